@@ -1,0 +1,192 @@
+/*
+ * swk.h -- C ABI of libswk.so, the MI355X (gfx950) implementation of
+ * swiftwatcher's per-frame segmentation hot path.
+ *
+ * The reference (joshuacwnewton/swiftwatcher) is pure Python and has no FFI of its
+ * own; the boundary it offers is its Python call surface
+ * (swiftwatcher/data_structures.py:116-217 FrameQueue.preprocess_queue/segment_queue,
+ * swiftwatcher/image_filtering.py:188-369 free functions).  Each entry point below
+ * names the reference function it replaces.  The ctypes binding a maintainer would add
+ * is shown in INTEGRATION.md and shipped in swiftwatcher_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = SWK_OK, negative = error;
+ *     swk_last_error(ctx) gives the text of the last failure on that context.
+ *   - plain pointers and sizes only.  Buffers are caller-allocated and C-contiguous;
+ *     the library never frees or retains a caller pointer after the call returns.
+ *   - "mem" fields say where a caller buffer lives: SWK_MEM_HOST (pageable or pinned
+ *     host memory; the library copies) or SWK_MEM_DEVICE (a HIP device pointer on the
+ *     context's GPU, e.g. torch.Tensor.data_ptr()).
+ *   - one swk_ctx per process per GPU; a context is not thread-safe; calls are
+ *     synchronous (work runs on the context's own HIP stream and is waited for).
+ *   - there is NO CPU fallback: without a usable gfx950 device swk_ctx_create fails
+ *     with SWK_ERR_NOGPU and nothing else can be called.
+ */
+#ifndef SWK_H
+#define SWK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWK_ABI_VERSION 1
+
+enum {
+    SWK_OK = 0,
+    SWK_ERR_ARG = -1,       /* bad argument / unsupported parameter value   */
+    SWK_ERR_HIP = -2,       /* a HIP runtime call failed                    */
+    SWK_ERR_NOGPU = -3,     /* no usable gfx950 device                      */
+    SWK_ERR_CAPACITY = -4,  /* request exceeds what the context was sized for */
+    SWK_ERR_NOMEM = -5
+};
+
+enum { SWK_MEM_HOST = 0, SWK_MEM_DEVICE = 1 };
+
+/* component numbering of cc_labeling (see swk_ccl_u8) */
+enum { SWK_ORDER_RASTER = 0, SWK_ORDER_BLOCK2X2 = 1 };
+
+/* BGR->gray fixed-point weights (see swk_bgr2gray) */
+enum { SWK_GRAY_Q14 = 0, SWK_GRAY_Q15 = 1 };
+
+typedef struct swk_ctx swk_ctx;
+
+/* Algorithm constants.  The reference hard-codes all of them; swk_params_default()
+ * fills in exactly those literals (file:line next to each field). */
+typedef struct swk_params {
+    double  lmbda;            /* IALM lambda = 0.01          image_filtering.py:256 */
+    double  tol;              /* IALM tolerance = 0.001      image_filtering.py:256 */
+    int32_t maxiter;          /* IALM max iterations = 100   image_filtering.py:257 */
+    int32_t bil_d;            /* bilateral diameter = 7      data_structures.py:194 */
+    double  bil_sigma_color;  /* = 15                        data_structures.py:194 */
+    double  bil_sigma_space;  /* = 1                         data_structures.py:194 */
+    int32_t bil_fma;          /* 0: sum += v*w (mul, add); 1: fused multiply-add.
+                                 OpenCV builds differ; unpinned, default 0          */
+    int32_t thresh;           /* THRESH_TOZERO level = 15    data_structures.py:198 */
+    int32_t open_kh, open_kw; /* grey opening window = 3,3   data_structures.py:202 */
+    int32_t connectivity;     /* 8: what cv2.connectedComponents(frame, 4) really runs
+                                 (the 4 lands in the `labels` slot, image_filtering.py:327);
+                                 4 also supported                                    */
+    int32_t label_order;      /* SWK_ORDER_BLOCK2X2 (OpenCV 8-way default, BBDT) or
+                                 SWK_ORDER_RASTER (SAUF; always used for 4-way)      */
+    int32_t gray_mode;        /* SWK_GRAY_Q14 = OpenCV 4.1.0 (requirements.txt:8)    */
+    int32_t reserved_;
+} swk_params;
+
+/* One region of one frame: what get_segment_properties()/regionprops yields that
+ * the rest of swiftwatcher reads (image_filtering.py:332-335, data_structures.py:16-30).
+ * bbox = (r0, c0, r1, c1) half-open; centroid = (sum_r/area, sum_c/area) -- the caller
+ * divides in float64, which is bit-identical to skimage's coords.mean(axis=0). */
+typedef struct swk_segment {
+    int32_t label;
+    int32_t r0, c0, r1, c1;
+    int32_t reserved_;
+    int64_t area;
+    int64_t sum_r, sum_c;
+} swk_segment;
+
+/* A batch of RPCA windows taken from a stream of frames.
+ * Window w, queue position j (0 = newest, data_structures.py:134) is the frame at
+ *   frames + (w*n + j)*frame_stride, pixel (r, c) of its ROI at
+ *   + (y0 + r)*row_stride + (x0 + c)*channels.
+ * Passing whole 1080p frames with (x0, y0, Hc, Wc) = crop_region reproduces
+ * crop_frame() (image_filtering.py:199-203); passing pre-cropped ROIs uses x0=y0=0. */
+typedef struct swk_input {
+    const uint8_t *frames;
+    int32_t mem;            /* SWK_MEM_HOST / SWK_MEM_DEVICE */
+    int32_t channels;       /* 3 = BGR (convert_grayscale runs), 1 = already gray (passes
+                               through, image_filtering.py:193-194) */
+    int32_t nwin;           /* windows in this batch */
+    int32_t n;              /* frames per window = FrameQueue queue_size (21 default) */
+    int32_t Hc, Wc;         /* ROI rows, cols */
+    int32_t x0, y0;         /* ROI origin inside each frame */
+    int64_t frame_stride;   /* bytes */
+    int64_t row_stride;     /* bytes */
+} swk_input;
+
+/* Every pointer is optional (NULL = not wanted).  Planes are u8 [nwin*n][Hc][Wc] in the
+ * same frame order as the input; they are the per-stage images FrameQueue stores under
+ * "grayscale", "RPCA", "bilateral", "thresh_15", "opened", "cc_labeling"
+ * (data_structures.py:183-208). */
+typedef struct swk_output {
+    int32_t mem;            /* where ALL non-NULL buffers below live */
+    int32_t seg_cap;        /* capacity of segs per frame (<= 255; labels are u8) */
+    uint8_t *gray, *rpca, *bilateral, *thresh, *opened, *labels;
+    double  *A, *E;         /* [nwin][Hc*Wc][n] float64, the reference's (pixels, frames)
+                               layout (image_filtering.py:235-237); E costs an extra
+                               8 B/element/iteration of HBM traffic when requested */
+    int32_t *iters;         /* [nwin] IALM iterations executed */
+    int32_t *nseg;          /* [nwin*n] regions found per frame (may exceed seg_cap) */
+    swk_segment *segs;      /* [nwin*n][seg_cap], ascending label */
+} swk_output;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+int32_t swk_abi_version(void);
+void    swk_params_default(swk_params *p);
+/* Sizes device workspaces for batches up to max_windows x max_n frames of max_Hc x max_Wc. */
+int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n,
+                       int32_t max_Hc, int32_t max_Wc, swk_ctx **out);
+void    swk_ctx_destroy(swk_ctx *ctx);
+const char *swk_last_error(const swk_ctx *ctx);   /* ctx may be NULL: last create error */
+/* Bytes of device memory the context holds (for sizing against 288 GB HBM). */
+int64_t swk_ctx_device_bytes(const swk_ctx *ctx);
+
+/* ---- the hot path --------------------------------------------------------------
+ * Replaces, for a batch of windows, FrameQueue.preprocess_queue + segment_queue
+ * (data_structures.py:171-217): crop -> gray -> RPCA/IALM -> bilateral -> to-zero
+ * threshold -> 3x3 grey opening -> connected components -> region properties.
+ * Windows are independent (no state is carried between them). */
+int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, swk_output *out);
+
+/* ---- stage-level entry points (host buffers; used by the parity tests and by the
+ *      image_filtering.* drop-in functions) ------------------------------------- */
+/* convert_grayscale (image_filtering.py:188-196): [count][H][W][3] -> [count][H][W] */
+int32_t swk_bgr2gray(swk_ctx *ctx, const uint8_t *bgr, int32_t count, int32_t H, int32_t W,
+                     int32_t gray_mode, uint8_t *gray);
+/* inexact_augmented_lagrange_multiplier (image_filtering.py:256-301) on one window.
+ * planes: u8 [n][P] (frame j = column j of the reference's X); A, E: float64 [P][n]. */
+int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P,
+                 double lmbda, double tol, int32_t maxiter,
+                 double *A, double *E, int32_t *iters);
+/* rpca() tail (image_filtering.py:244-245): S = clip(-E, 0, 255).astype(uint8) */
+int32_t swk_rpca_epilogue(swk_ctx *ctx, const double *E, int64_t count, uint8_t *S);
+/* bilateral_blur (image_filtering.py:304-307): [count][H][W] u8 */
+int32_t swk_bilateral_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W,
+                         int32_t d, double sigma_color, double sigma_space, int32_t use_fma,
+                         uint8_t *dst);
+/* thresh_to_zero (image_filtering.py:310-316) */
+int32_t swk_thresh_tozero_u8(swk_ctx *ctx, const uint8_t *src, int64_t count, int32_t thresh,
+                             uint8_t *dst);
+/* grayscale_opening with SE (3,3) (image_filtering.py:319-322): [count][H][W] u8 */
+int32_t swk_grey_open3x3_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W,
+                            uint8_t *dst);
+/* cc_labeling (image_filtering.py:325-329) before the uint8 cast: int32 labels, and the
+ * component count per plane. */
+int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W,
+                   int32_t connectivity, int32_t label_order, int32_t *labels, int32_t *ncomp);
+/* get_segment_properties (image_filtering.py:332-335) on u8 label planes. */
+int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, int32_t H, int32_t W,
+                           int32_t seg_cap, swk_segment *segs, int32_t *nseg);
+
+/* ---- measurement hooks -----------------------------------------------------------
+ * With profiling on, every kernel launch of swk_batch_run is bracketed by HIP events on
+ * the context's stream; swk_prof_get returns accumulated device time and launch count per
+ * kernel family since the last swk_prof_reset.  Family ids: */
+enum {
+    SWK_K_GRAY = 0, SWK_K_IALM_STATS = 1, SWK_K_IALM_PASS = 2, SWK_K_IALM_SMALL = 3,
+    SWK_K_FILTER = 4, SWK_K_CCL = 5, SWK_K_PROPS = 6, SWK_K_COPY = 7, SWK_K_COUNT = 8
+};
+int32_t swk_prof_enable(swk_ctx *ctx, int32_t on);
+int32_t swk_prof_reset(swk_ctx *ctx);
+int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *launches);
+/* Total IALM pass launches x windows still active, i.e. window-iterations streamed. */
+int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
+/* Select the IALM pass kernel: 0 = auto, 1 = LDS/VALU kernel (any n <= 64),
+ * 2 = MFMA f64 kernel.  For A/B measurements only. */
+int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWK_H */

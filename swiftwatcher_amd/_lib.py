@@ -1,0 +1,302 @@
+"""ctypes binding of libswk.so (include/swk.h).  No torch, no numpy arithmetic: this module
+only marshals pointers.  There is no CPU fallback -- if the HIP library is missing or no
+gfx950 device is usable, importing is fine but creating a Context raises SwkError."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswk.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ORDER_RASTER, ORDER_BLOCK2X2 = 0, 1
+GRAY_Q14, GRAY_Q15 = 0, 1
+K_GRAY, K_IALM_STATS, K_IALM_PASS, K_IALM_SMALL, K_FILTER, K_CCL, K_PROPS, K_COPY = range(8)
+KERNEL_FAMILIES = ["gray", "ialm_stats", "ialm_pass", "ialm_small", "filter", "ccl", "props", "copy"]
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class SwkError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("lmbda", ctypes.c_double), ("tol", ctypes.c_double), ("maxiter", ctypes.c_int32),
+                ("bil_d", ctypes.c_int32), ("bil_sigma_color", ctypes.c_double),
+                ("bil_sigma_space", ctypes.c_double), ("bil_fma", ctypes.c_int32),
+                ("thresh", ctypes.c_int32), ("open_kh", ctypes.c_int32), ("open_kw", ctypes.c_int32),
+                ("connectivity", ctypes.c_int32), ("label_order", ctypes.c_int32),
+                ("gray_mode", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
+class Segment(ctypes.Structure):
+    _fields_ = [("label", ctypes.c_int32), ("r0", ctypes.c_int32), ("c0", ctypes.c_int32),
+                ("r1", ctypes.c_int32), ("c1", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("area", ctypes.c_int64), ("sum_r", ctypes.c_int64), ("sum_c", ctypes.c_int64)]
+
+
+SEGMENT_DTYPE = np.dtype([("label", "<i4"), ("r0", "<i4"), ("c0", "<i4"), ("r1", "<i4"), ("c1", "<i4"),
+                          ("reserved_", "<i4"), ("area", "<i8"), ("sum_r", "<i8"), ("sum_c", "<i8")])
+assert SEGMENT_DTYPE.itemsize == ctypes.sizeof(Segment) == 48
+
+
+class Input(ctypes.Structure):
+    _fields_ = [("frames", ctypes.c_void_p), ("mem", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("nwin", ctypes.c_int32), ("n", ctypes.c_int32), ("Hc", ctypes.c_int32), ("Wc", ctypes.c_int32),
+                ("x0", ctypes.c_int32), ("y0", ctypes.c_int32),
+                ("frame_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64)]
+
+
+class Output(ctypes.Structure):
+    _fields_ = [("mem", ctypes.c_int32), ("seg_cap", ctypes.c_int32),
+                ("gray", ctypes.c_void_p), ("rpca", ctypes.c_void_p), ("bilateral", ctypes.c_void_p),
+                ("thresh", ctypes.c_void_p), ("opened", ctypes.c_void_p), ("labels", ctypes.c_void_p),
+                ("A", ctypes.c_void_p), ("E", ctypes.c_void_p),
+                ("iters", ctypes.c_void_p), ("nseg", ctypes.c_void_p), ("segs", ctypes.c_void_p)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_SIGS = {
+    "swk_abi_version": (ctypes.c_int32, []),
+    "swk_params_default": (None, [ctypes.POINTER(Params)]),
+    "swk_ctx_create": (ctypes.c_int32, [ctypes.c_int32] * 5 + [ctypes.POINTER(ctypes.c_void_p)]),
+    "swk_ctx_destroy": (None, [ctypes.c_void_p]),
+    "swk_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "swk_ctx_device_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
+    "swk_batch_run": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(Input), ctypes.POINTER(Params), ctypes.POINTER(Output)]),
+    "swk_bgr2gray": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_ialm": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_rpca_epilogue": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "swk_bilateral_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_thresh_tozero_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_grey_open3x3_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
+    "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def load():
+    """dlopen libswk.so and type its entry points.  Raises SwkError when the library has not
+    been built (python swiftwatcher_amd/csrc/build.py) -- never falls back to anything."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise SwkError("libswk.so not built: run `python swiftwatcher_amd/csrc/build.py` "
+                               "(there is no CPU fallback)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(lib, name)          # AttributeError = ABI mismatch, let it surface
+                fn.restype = res
+                fn.argtypes = args
+            if lib.swk_abi_version() != 1:
+                raise SwkError("libswk.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def default_params(**overrides):
+    p = Params()
+    load().swk_params_default(ctypes.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown swk parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Context:
+    """One per process per GPU (swk_ctx).  Not thread-safe."""
+
+    def __init__(self, device=0, max_windows=0, max_n=0, max_Hc=0, max_Wc=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.swk_ctx_create(device, max_windows, max_n, max_Hc, max_Wc, ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.swk_last_error(None)
+            self._h = None
+            raise SwkError("swk_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.swk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.swk_last_error(self._h)
+            raise SwkError("libswk error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    @property
+    def device_bytes(self):
+        return int(self._lib.swk_ctx_device_bytes(self._h))
+
+    # ---- profiling hooks ----
+    def prof_enable(self, on=True):
+        self._check(self._lib.swk_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        self._check(self._lib.swk_prof_reset(self._h))
+
+    def prof(self):
+        out = {}
+        for i, name in enumerate(KERNEL_FAMILIES):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            self._check(self._lib.swk_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = (ms.value, n.value)
+        wi = ctypes.c_int64()
+        self._check(self._lib.swk_prof_window_iters(self._h, ctypes.byref(wi)))
+        out["window_iters"] = wi.value
+        return out
+
+    def set_ialm_variant(self, variant):
+        self._check(self._lib.swk_set_ialm_variant(self._h, int(variant)))
+
+    # ---- hot path ----
+    def batch_run_raw(self, inp, params, out):
+        self._check(self._lib.swk_batch_run(self._h, ctypes.byref(inp), ctypes.byref(params), ctypes.byref(out)))
+
+    def batch_run(self, frames, nwin, n, crop=None, params=None, stages=("gray", "rpca", "bilateral", "thresh", "opened", "labels"),
+                  want_A=False, want_E=False, seg_cap=255):
+        """Host-buffer convenience wrapper.
+
+        frames: u8 array (nwin*n, H, W, 3) or (nwin*n, H, W), C-contiguous in the last two/three axes
+        crop:   (x0, y0, Wc, Hc) inside each frame, or None for the whole frame
+        Returns dict with the requested stage stacks (nwin*n, Hc, Wc) u8, 'iters' (nwin,),
+        'nseg' (nwin*n,), 'segs' structured array (nwin*n, seg_cap), optionally 'A'/'E' (nwin, P, n).
+        """
+        params = params or default_params()
+        F = nwin * n
+        if frames.dtype != np.uint8 or frames.shape[0] != F or frames.ndim not in (3, 4):
+            raise ValueError("frames must be uint8 (nwin*n, H, W[, 3])")
+        ch = 1 if frames.ndim == 3 else frames.shape[3]
+        if frames.ndim == 4 and (frames.strides[3] != 1 or frames.strides[2] != ch):
+            raise ValueError("frames must be contiguous along columns/channels")
+        if frames.ndim == 3 and frames.strides[2] != 1:
+            raise ValueError("frames must be contiguous along columns")
+        H, W = frames.shape[1], frames.shape[2]
+        x0, y0, Wc, Hc = crop if crop is not None else (0, 0, W, H)
+        if x0 < 0 or y0 < 0 or x0 + Wc > W or y0 + Hc > H:
+            raise ValueError("crop rectangle outside the frame")
+        inp = Input(frames=frames.ctypes.data, mem=MEM_HOST, channels=ch, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
+                    x0=x0, y0=y0, frame_stride=frames.strides[0], row_stride=frames.strides[1])
+        res = {}
+        out = Output(mem=MEM_HOST, seg_cap=seg_cap)
+        for name in stages:
+            res[name] = np.empty((F, Hc, Wc), np.uint8)
+            setattr(out, name, res[name].ctypes.data)
+        P = Hc * Wc
+        if want_A:
+            res["A"] = np.empty((nwin, P, n), np.float64)
+            out.A = res["A"].ctypes.data
+        if want_E:
+            res["E"] = np.empty((nwin, P, n), np.float64)
+            out.E = res["E"].ctypes.data
+        res["iters"] = np.zeros(nwin, np.int32)
+        res["nseg"] = np.zeros(F, np.int32)
+        res["segs"] = np.zeros((F, seg_cap), SEGMENT_DTYPE)
+        out.iters = res["iters"].ctypes.data
+        out.nseg = res["nseg"].ctypes.data
+        out.segs = res["segs"].ctypes.data
+        self.batch_run_raw(inp, params, out)
+        return res
+
+    # ---- stage-level entry points ----
+    def bgr2gray(self, bgr, gray_mode=GRAY_Q14):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        single = bgr.ndim == 3
+        b4 = bgr[None] if single else bgr
+        cnt, H, W, _ = b4.shape
+        out = np.empty((cnt, H, W), np.uint8)
+        self._check(self._lib.swk_bgr2gray(self._h, _ptr(b4), cnt, H, W, gray_mode, _ptr(out)))
+        return out[0] if single else out
+
+    def ialm(self, planes, lmbda=0.01, tol=0.001, maxiter=100, want_E=True):
+        """planes: u8 (n, P).  Returns A (P, n), E (P, n) or None, iterations."""
+        planes = np.ascontiguousarray(planes, np.uint8)
+        n, P = planes.shape
+        A = np.empty((P, n), np.float64)
+        E = np.empty((P, n), np.float64) if want_E else None
+        it = np.zeros(1, np.int32)
+        self._check(self._lib.swk_ialm(self._h, _ptr(planes), n, P, lmbda, tol, maxiter, _ptr(A), _ptr(E), _ptr(it)))
+        return A, E, int(it[0])
+
+    def rpca_epilogue(self, E):
+        E = np.ascontiguousarray(E, np.float64)
+        out = np.empty(E.shape, np.uint8)
+        self._check(self._lib.swk_rpca_epilogue(self._h, _ptr(E), E.size, _ptr(out)))
+        return out
+
+    def _planes(self, a):
+        a = np.ascontiguousarray(a, np.uint8)
+        return (a[None], True) if a.ndim == 2 else (a, False)
+
+    def bilateral_u8(self, src, d=7, sigma_color=15.0, sigma_space=1.0, use_fma=False):
+        s, single = self._planes(src)
+        out = np.empty_like(s)
+        self._check(self._lib.swk_bilateral_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], d,
+                                               sigma_color, sigma_space, int(bool(use_fma)), _ptr(out)))
+        return out[0] if single else out
+
+    def thresh_tozero_u8(self, src, thresh=15):
+        s = np.ascontiguousarray(src, np.uint8)
+        out = np.empty_like(s)
+        self._check(self._lib.swk_thresh_tozero_u8(self._h, _ptr(s), s.size, thresh, _ptr(out)))
+        return out
+
+    def grey_open3x3_u8(self, src):
+        s, single = self._planes(src)
+        out = np.empty_like(s)
+        self._check(self._lib.swk_grey_open3x3_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], _ptr(out)))
+        return out[0] if single else out
+
+    def ccl_u8(self, src, connectivity=8, label_order=ORDER_BLOCK2X2):
+        s, single = self._planes(src)
+        lab = np.empty(s.shape, np.int32)
+        nc = np.zeros(s.shape[0], np.int32)
+        self._check(self._lib.swk_ccl_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], connectivity,
+                                         label_order, _ptr(lab), _ptr(nc)))
+        return (int(nc[0]), lab[0]) if single else (nc, lab)
+
+    def regionprops_u8(self, labels, seg_cap=255):
+        s, single = self._planes(labels)
+        segs = np.zeros((s.shape[0], seg_cap), SEGMENT_DTYPE)
+        nseg = np.zeros(s.shape[0], np.int32)
+        self._check(self._lib.swk_regionprops_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], seg_cap,
+                                                 _ptr(segs), _ptr(nseg)))
+        return (segs[0, :nseg[0]], int(nseg[0])) if single else (segs, nseg)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context used by the image_filtering.* drop-in functions."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,298 @@
+// Byte-image stages of the segment path on gfx950:
+//   crop + BGR2GRAY      (image_filtering.py:199-203, 188-196)
+//   bilateral filter      (image_filtering.py:304-307; OpenCV 4.1.0 bilateralFilter_8u semantics)
+//   to-zero threshold     (image_filtering.py:310-316)
+//   3x3 grey opening      (image_filtering.py:319-322; scipy.ndimage.grey_opening, mode 'reflect')
+// All HBM-bound u8 work: one read of the sparse image, one write of the opened image, tiles
+// staged in LDS with their halos.  Float arithmetic of the bilateral filter is IEEE f32 with
+// contraction off (the library is built with -ffp-contract=off) so results are bit-identical
+// to a scalar C evaluation in the same tap order.
+#include "swk_internal.h"
+
+namespace swk {
+
+// ---------------------------------------------------------------------------------
+// crop + gray.  OpenCV 4.1.0 RGB2Gray<uchar>: (B*1868 + G*9617 + R*4899 + 2^13) >> 14.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ frames, int channels,
+                                              int64_t frame_stride, int64_t row_stride, int x0, int y0,
+                                              int H, int W, int mode, uint8_t *__restrict__ out)
+{
+    const int f = blockIdx.z, r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const uint8_t *src = frames + (int64_t)f * frame_stride + (int64_t)(y0 + r) * row_stride + (int64_t)(x0 + c) * channels;
+    int y;
+    if (channels == 1) {
+        y = src[0];
+    } else {
+        const int bb = src[0], gg = src[1], rr = src[2];
+        if (mode == SWK_GRAY_Q14) y = (bb * 1868 + gg * 9617 + rr * 4899 + (1 << 13)) >> 14;
+        else y = (bb * 3735 + gg * 19235 + rr * 9798 + (1 << 14)) >> 15;
+    }
+    out[((int64_t)f * H + r) * W + c] = (uint8_t)y;
+}
+
+void launch_gray(hipStream_t s, const uint8_t *frames, int channels, int64_t frame_stride, int64_t row_stride,
+                 int x0, int y0, int F, int H, int W, int gray_mode, uint8_t *out)
+{
+    // grid.z is limited to 65535: split the frame range
+    for (int f0 = 0; f0 < F; f0 += 32768) {
+        const int fc = F - f0 < 32768 ? F - f0 : 32768;
+        hipLaunchKernelGGL(k_gray, dim3((W + 255) / 256, H, fc), dim3(256), 0, s,
+                           frames + (int64_t)f0 * frame_stride, channels, frame_stride, row_stride, x0, y0, H, W,
+                           gray_mode, out + (int64_t)f0 * H * W);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+__device__ __forceinline__ int clampi(int p, int len) { return p < 0 ? 0 : (p >= len ? len - 1 : p); }
+
+constexpr int kMaxTaps = 81;   // radius <= 4 (d <= 9)
+
+// Generic bilateral (any radius <= 4), one thread per pixel, global reads (L1/L2 absorb the reuse).
+// Stage-level entry point; the hot path uses the fused tile kernel below.
+__global__ __launch_bounds__(256) void k_bilateral(const uint8_t *__restrict__ src, int H, int W,
+                                                   const float *__restrict__ color_w, const float *__restrict__ space_w,
+                                                   const int8_t *__restrict__ tdr, const int8_t *__restrict__ tdc,
+                                                   int maxk, int use_fma, uint8_t *__restrict__ dst)
+{
+    __shared__ float s_cw[256];
+    __shared__ float s_sw[kMaxTaps];
+    __shared__ int s_dr[kMaxTaps], s_dc[kMaxTaps];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cw[i] = color_w[i];
+    for (int i = threadIdx.x; i < maxk; i += blockDim.x) { s_sw[i] = space_w[i]; s_dr[i] = tdr[i]; s_dc[i] = tdc[i]; }
+    __syncthreads();
+    const int f = blockIdx.z, r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const uint8_t *img = src + (int64_t)f * H * W;
+    const int v0 = img[r * W + c];
+    float sum = 0.f, wsum = 0.f;
+    for (int k = 0; k < maxk; ++k) {
+        const int rr = reflect101(r + s_dr[k], H), cc = reflect101(c + s_dc[k], W);
+        const int v = img[rr * W + cc];
+        const int dv = v - v0;
+        const float w = s_sw[k] * s_cw[dv < 0 ? -dv : dv];
+        if (use_fma) sum = __fmaf_rn((float)v, w, sum);
+        else sum = sum + (float)v * w;
+        wsum = wsum + w;
+    }
+    dst[((int64_t)f * H + r) * W + c] = (uint8_t)__float2int_rn(sum / wsum);     // cvRound: half to even
+}
+
+void launch_bilateral(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
+                      int use_fma, uint8_t *dst)
+{
+    for (int f0 = 0; f0 < F; f0 += 32768) {
+        const int fc = F - f0 < 32768 ? F - f0 : 32768;
+        hipLaunchKernelGGL(k_bilateral, dim3((W + 255) / 256, H, fc), dim3(256), 0, s, src + (int64_t)f0 * H * W, H, W,
+                           t.color_w, t.space_w, t.tap_dr, t.tap_dc, t.maxk, use_fma, dst + (int64_t)f0 * H * W);
+    }
+}
+
+__global__ void k_thresh(const uint8_t *__restrict__ src, int64_t count, int thresh, uint8_t *__restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = src[i];
+        dst[i] = v > thresh ? (uint8_t)v : (uint8_t)0;
+    }
+}
+
+void launch_thresh(hipStream_t s, const uint8_t *src, int64_t count, int thresh, uint8_t *dst)
+{
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_thresh, dim3((unsigned)blocks), dim3(256), 0, s, src, count, thresh, dst);
+}
+
+// 3x3 grey opening = min3x3 then max3x3; scipy's 'reflect' border equals clamp-to-edge at radius 1.
+// Tile 32x64 outputs; erosion is needed on a 1-px ring, the source on a 2-px ring.
+constexpr int kTH = 32, kTW = 64;
+
+__global__ __launch_bounds__(256) void k_open3x3(const uint8_t *__restrict__ src, int H, int W, uint8_t *__restrict__ dst)
+{
+    __shared__ uint8_t s_in[(kTH + 4) * (kTW + 4)];
+    __shared__ uint8_t s_er[(kTH + 2) * (kTW + 2)];
+    const int f = blockIdx.z;
+    const int r0 = blockIdx.y * kTH, c0 = blockIdx.x * kTW;
+    const uint8_t *img = src + (int64_t)f * H * W;
+    for (int i = threadIdx.x; i < (kTH + 4) * (kTW + 4); i += blockDim.x) {
+        const int lr = i / (kTW + 4), lc = i % (kTW + 4);
+        const int r = clampi(r0 + lr - 2, H), c = clampi(c0 + lc - 2, W);
+        s_in[i] = img[r * W + c];
+    }
+    __syncthreads();
+    // erosion at image positions (r0-1+lr, c0-1+lc); window coordinates clamp to the IMAGE
+    for (int i = threadIdx.x; i < (kTH + 2) * (kTW + 2); i += blockDim.x) {
+        const int lr = i / (kTW + 2), lc = i % (kTW + 2);
+        const int r = clampi(r0 + lr - 1, H), c = clampi(c0 + lc - 1, W);
+        int acc = 255;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
+                const int v = s_in[(rr - r0 + 2) * (kTW + 4) + (cc - c0 + 2)];
+                acc = v < acc ? v : acc;
+            }
+        s_er[i] = (uint8_t)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
+        const int lr = i / kTW, lc = i % kTW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= H || c >= W) continue;
+        int acc = 0;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
+                const int v = s_er[(rr - r0 + 1) * (kTW + 2) + (cc - c0 + 1)];
+                acc = v > acc ? v : acc;
+            }
+        dst[((int64_t)f * H + r) * W + c] = (uint8_t)acc;
+    }
+}
+
+void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint8_t *dst)
+{
+    for (int f0 = 0; f0 < F; f0 += 32768) {
+        const int fc = F - f0 < 32768 ? F - f0 : 32768;
+        hipLaunchKernelGGL(k_open3x3, dim3((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, fc), dim3(256), 0, s,
+                           src + (int64_t)f0 * H * W, H, W, dst + (int64_t)f0 * H * W);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Fused hot-path kernel: bilateral (radius 3, 29 taps) -> to-zero threshold -> 3x3 opening.
+// One 32x64 output tile per workgroup.  Rings: opening needs the thresholded image on a 2-px
+// ring, the bilateral filter needs the sparse image 3 px beyond that: a (32+10)x(64+10) source
+// tile in LDS, read once from HBM.  The sparse image is mostly zero: a pixel whose whole
+// neighbourhood is zero is zero after the filter (sum = 0), so an all-zero source tile skips
+// the arithmetic altogether.
+// ---------------------------------------------------------------------------------
+constexpr int kR = 3;                    // bilateral radius of the fused kernel
+constexpr int kSH = kTH + 4 + 2 * kR;    // 42
+constexpr int kSW = kTW + 4 + 2 * kR;    // 74
+constexpr int kBH = kTH + 4, kBW = kTW + 4;
+
+__global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict__ src, int H, int W,
+                                                      const float *__restrict__ color_w, const float *__restrict__ space_w,
+                                                      const int8_t *__restrict__ tdr, const int8_t *__restrict__ tdc,
+                                                      int maxk, int use_fma, int thresh,
+                                                      uint8_t *__restrict__ bil_out, uint8_t *__restrict__ thr_out,
+                                                      uint8_t *__restrict__ open_out)
+{
+    __shared__ uint8_t s_src[kSH * kSW];
+    __shared__ uint8_t s_thr[kBH * kBW];
+    __shared__ uint8_t s_er[(kTH + 2) * (kTW + 2)];
+    __shared__ float s_cw[256];
+    __shared__ float s_sw[32];
+    __shared__ int s_ofs[32];
+    __shared__ int s_any;
+    const int f = blockIdx.z;
+    const int r0 = blockIdx.y * kTH, c0 = blockIdx.x * kTW;
+    const uint8_t *img = src + (int64_t)f * H * W;
+    if (threadIdx.x == 0) s_any = 0;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cw[i] = color_w[i];
+    if (threadIdx.x < maxk) {
+        s_sw[threadIdx.x] = space_w[threadIdx.x];
+        s_ofs[threadIdx.x] = (int)tdr[threadIdx.x] * kSW + (int)tdc[threadIdx.x];
+    }
+    __syncthreads();
+    int any = 0;
+    for (int i = threadIdx.x; i < kSH * kSW; i += blockDim.x) {
+        const int lr = i / kSW, lc = i % kSW;
+        // Cell (lr, lc) stands for image coordinate (r0+lr-5, c0+lc-5).  Taps of in-image pixels
+        // reach outside the image by up to kR and use BORDER_REFLECT_101 there, so every cell
+        // holds img[reflect101(coordinate)]; cells far outside the image are never consumed.
+        const int r = reflect101(r0 + lr - 2 - kR, H);
+        const int c = reflect101(c0 + lc - 2 - kR, W);
+        const uint8_t v = img[r * W + c];
+        s_src[i] = v;
+        any |= v;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    const bool nonzero = s_any != 0;
+    // bilateral + threshold on the (32+4)x(64+4) ring, in-image cells only
+    for (int i = threadIdx.x; i < kBH * kBW; i += blockDim.x) {
+        const int lr = i / kBW, lc = i % kBW;
+        const int r = r0 + lr - 2, c = c0 + lc - 2;
+        uint8_t outv = 0;
+        if (nonzero && r >= 0 && r < H && c >= 0 && c < W) {
+            const int ctr = (lr + kR) * kSW + (lc + kR);
+            const int v0 = s_src[ctr];
+            float sum = 0.f, wsum = 0.f;
+            for (int k = 0; k < maxk; ++k) {
+                const int v = s_src[ctr + s_ofs[k]];
+                const int dv = v - v0;
+                const float w = s_sw[k] * s_cw[dv < 0 ? -dv : dv];
+                if (use_fma) sum = __fmaf_rn((float)v, w, sum);
+                else sum = sum + (float)v * w;
+                wsum = wsum + w;
+            }
+            outv = (uint8_t)__float2int_rn(sum / wsum);
+        }
+        const bool interior = lr >= 2 && lr < kBH - 2 && lc >= 2 && lc < kBW - 2 && r < H && c < W;
+        if (interior && bil_out) bil_out[((int64_t)f * H + r) * W + c] = outv;
+        outv = outv > thresh ? outv : (uint8_t)0;
+        if (interior && thr_out) thr_out[((int64_t)f * H + r) * W + c] = outv;
+        s_thr[i] = outv;
+    }
+    __syncthreads();
+    if (!nonzero) {
+        for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
+            const int r = r0 + i / kTW, c = c0 + i % kTW;
+            if (r < H && c < W) open_out[((int64_t)f * H + r) * W + c] = 0;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < (kTH + 2) * (kTW + 2); i += blockDim.x) {
+        const int lr = i / (kTW + 2), lc = i % (kTW + 2);
+        const int r = clampi(r0 + lr - 1, H), c = clampi(c0 + lc - 1, W);
+        int acc = 255;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
+                const int v = s_thr[(rr - r0 + 2) * kBW + (cc - c0 + 2)];
+                acc = v < acc ? v : acc;
+            }
+        s_er[i] = (uint8_t)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
+        const int lr = i / kTW, lc = i % kTW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= H || c >= W) continue;
+        int acc = 0;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
+                const int v = s_er[(rr - r0 + 1) * (kTW + 2) + (cc - c0 + 1)];
+                acc = v > acc ? v : acc;
+            }
+        open_out[((int64_t)f * H + r) * W + c] = (uint8_t)acc;
+    }
+}
+
+void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
+                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out)
+{
+    for (int f0 = 0; f0 < F; f0 += 32768) {
+        const int fc = F - f0 < 32768 ? F - f0 : 32768;
+        const int64_t o = (int64_t)f0 * H * W;
+        hipLaunchKernelGGL(k_filter_fused, dim3((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, fc), dim3(256), 0, s,
+                           src + o, H, W, t.color_w, t.space_w, t.tap_dr, t.tap_dc, t.maxk, use_fma, thresh,
+                           bil_out ? bil_out + o : nullptr, thr_out ? thr_out + o : nullptr, open_out + o);
+    }
+}
+
+}  // namespace swk

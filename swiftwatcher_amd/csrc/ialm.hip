@@ -1,0 +1,424 @@
+// RPCA by inexact ALM on gfx950 -- replaces image_filtering.py:220-301 of the reference.
+//
+// Formulation.  The reference's singular-value step keeps ALL singular values
+// (`svp = (S > 1/mu).shape[0]`, image_filtering.py:285, is the vector's length), so
+//     A = U diag(S - 1/mu) V^T = M - (1/mu) * polar(M),   polar(M) = M (M^T M)^(-1/2).
+// No SVD of the (pixels x frames) matrix is needed: one streaming pass accumulates the
+// n x n Gram matrix G = M^T M, a one-workgroup Jacobi eigen-solve turns it into
+// B = I - G^(-1/2)/mu, and the next streaming pass applies A = M B while already
+// accumulating the Gram matrix of the following iteration.  Per iteration every element
+// is read once (X u8, A f64, Y f64) and written once (A, Y, + the u8 sparse image):
+// 34 bytes.  E and M are recomputed, never stored.
+//
+// Data layout in HBM: frame-major planes.  X u8 [win][n][P], A/Y f64 [win][n][P]; a
+// wave reads 64 consecutive pixels of one frame per instruction (512 B for f64).
+//
+// All-zero frames (the null frames io_video.py:40-44 pads the last window with) give G a
+// zero eigenvalue; the reference leaves that direction to LAPACK (arbitrary), here it gets
+// weight 0, i.e. null frames are excluded from the decomposition.
+#include "swk_internal.h"
+
+namespace swk {
+
+// ---------------------------------------------------------------------------------
+// statistics: exact integer sum of squares and max of each window (image_filtering.py:269-275)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ialm_stats(const uint8_t *__restrict__ X, IalmWin *win, int64_t per_win)
+{
+    const int w = blockIdx.y;
+    const uint8_t *x = X + (int64_t)w * per_win;
+    unsigned long long ss = 0;
+    unsigned int mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_win; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned int v = x[i];
+        ss += v * v;
+        mx = v > mx ? v : mx;
+    }
+    for (int off = 32; off; off >>= 1) {
+        ss += __shfl_down(ss, off);
+        unsigned int o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {          // integer atomics: exact, order independent
+        atomicAdd(&win[w].sumsq, ss);
+        atomicMax(&win[w].maxv, mx);
+    }
+}
+
+__global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda)
+{
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    IalmWin &s = win[w];
+    double norm_two = sqrt((double)s.sumsq);            // :269 (= Frobenius norm of the window)
+    double norm_inf = (double)s.maxv / lmbda;           // :270
+    s.dual_norm = norm_two > norm_inf ? norm_two : norm_inf;   // :271
+    s.dnorm = norm_two;                                  // :275
+    s.nxt.mu = 1.25 / norm_two;                          // :276
+    s.nxt.inv_mu = 1.0 / s.nxt.mu;
+    s.nxt.thr = lmbda / s.nxt.mu;
+    s.cur = s.nxt;
+    s.iter = 0;
+    s.sweeps = 0;
+    // an all-zero window has nothing to decompose (the reference would divide by zero)
+    s.done = s.sumsq == 0 ? 1 : 0;
+    if (!s.done) atomicAdd(active, 1);
+}
+
+__device__ __forceinline__ double shrink(double raw, double thr)
+{
+    // np.maximum(raw - thr, 0) + np.minimum(raw + thr, 0)          :283
+    return fmax(raw - thr, 0.0) + fmin(raw + thr, 0.0);
+}
+
+__device__ __forceinline__ uint8_t sparse_u8(double e)
+{
+    double v = -e;                                       // :244
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);        // :245 clip
+    return (uint8_t)v;                                   // astype(uint8) truncates
+}
+
+// ---------------------------------------------------------------------------------
+// Variant 1: one wave per 64-pixel tile, frames looped at run time, products on the f64
+// VALU with the tile staged in LDS.  Works for every n <= 64; it is the fallback and the
+// on-device cross-check of the MFMA kernel.
+//   MODE 0: implicit start state (A=0, Y=X/dual_norm); only accumulates Gram(M_1)
+//   MODE 1: first full iteration, previous state implicit (no A/Y reads)
+//   MODE 2: steady state
+// ---------------------------------------------------------------------------------
+constexpr int kLdsRow = 65;
+
+template <int MODE, bool WRITE_E>
+__global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
+{
+    extern __shared__ double lds[];
+    const int n = b.n, P = b.P;
+    const int n8 = (n + 7) & ~7;
+    double *sm = lds;                    // [n8][65]  M of the iteration being finished
+    double *se = lds + n8 * kLdsRow;     // [n8][65]  E of it, then M of the next iteration
+    const int w = blockIdx.y;
+    const IalmWin &st = b.win[w];
+    if (st.done) return;
+    const int t = threadIdx.x;
+    const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
+    const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
+    const double dual = st.dual_norm;
+    const int64_t wbase = (int64_t)w * n * P;
+    const uint8_t *X = b.X + wbase;
+    double *A = b.A + wbase, *Y = b.Y + wbase;
+    uint8_t *S = b.S + wbase;
+    double *Eo = WRITE_E ? b.E + wbase : nullptr;
+    const double *Bm = b.Bm + (int64_t)w * n * n;
+
+    for (int j = n; j < n8; ++j) { sm[j * kLdsRow + t] = 0.0; se[j * kLdsRow + t] = 0.0; }
+
+    const int ti = t >> 3, tj = t & 7;
+    double g[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[a][c] = 0.0;
+    double zz = 0.0;
+
+    const int ntiles = (P + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p = tile * 64 + t;
+        const bool valid = p < P;
+        const int pc = valid ? p : P - 1;
+        if (MODE != 0) {
+            for (int j = 0; j < n; ++j) {
+                const int64_t idx = (int64_t)j * P + pc;
+                const double x = (double)X[idx];
+                double a, y;
+                if (MODE == 1) { a = 0.0; y = x / dual; }                 // :272-273
+                else { a = A[idx]; y = Y[idx]; }
+                const double raw = (x - a) + inv_mu * y;                  // :282
+                const double e = shrink(raw, thr);                        // :283
+                const double m = (x - e) + inv_mu * y;                    // :284 (SVD input)
+                sm[j * kLdsRow + t] = m;
+                se[j * kLdsRow + t] = e;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const int64_t idx = (int64_t)i * P + pc;
+            const double x = (double)X[idx];
+            double a_new, y;
+            if (MODE == 0) {
+                a_new = 0.0;
+                y = x / dual;
+            } else {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j) acc += sm[j * kLdsRow + t] * Bm[j * n + i];   // :290
+                a_new = acc;
+                const double e = se[i * kLdsRow + t];
+                const double z = (x - a_new) - e;                         // :293
+                const double y_prev = MODE == 1 ? x / dual : Y[idx];
+                y = y_prev + mu * z;                                      // :294
+                if (valid) {
+                    zz += z * z;
+                    A[idx] = a_new;
+                    Y[idx] = y;
+                    S[idx] = sparse_u8(e);
+                    if (WRITE_E) Eo[idx] = e;
+                }
+            }
+            const double raw2 = (x - a_new) + inv_mu2 * y;
+            const double e2 = shrink(raw2, thr2);
+            const double m2 = (x - e2) + inv_mu2 * y;
+            se[i * kLdsRow + t] = valid ? m2 : 0.0;
+        }
+        __syncthreads();
+        // Gram of the 64-pixel tile: thread (ti, tj) owns rows 8ti.., cols 8tj..
+        if (8 * ti < n && 8 * tj < n) {
+            for (int q = 0; q < 64; ++q) {
+                double ra[8], rb[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) ra[a] = se[(8 * ti + a) * kLdsRow + q];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rb[c] = se[(8 * tj + c) * kLdsRow + q];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) g[a][c] += ra[a] * rb[c];
+            }
+        }
+        __syncthreads();
+    }
+    double *gp = b.gpart + ((int64_t)w * b.nblk + blockIdx.x) * n * n;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = 8 * ti + a, j = 8 * tj + c;
+            if (i < n && j < n) gp[i * n + j] = g[a][c];
+        }
+    if (MODE != 0) {
+        for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
+        if (t == 0) b.zzpart[(int64_t)w * b.nblk + blockIdx.x] = zz;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// One workgroup per window: convergence test, mu update, Gram reduction, Jacobi
+// eigen-solve of G (n x n, f64, in LDS), B = I - G^(-1/2)/mu.
+// ---------------------------------------------------------------------------------
+constexpr int kJac = 65;    // LDS row pitch of the n x n matrices
+
+__device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, int &q)
+{
+    if (k == 0) { p = m - 1; q = r; }
+    else { p = (r + k) % (m - 1); q = (r - k + (m - 1)) % (m - 1); }
+    if (p > q) { int tmp = p; p = q; q = tmp; }
+}
+
+__global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter)
+{
+    __shared__ double G[kMaxN * kJac];
+    __shared__ double V[kMaxN * kJac];
+    __shared__ double red[256];
+    __shared__ double cs_c[kMaxN / 2], cs_s[kMaxN / 2];
+    __shared__ int pq_p[kMaxN / 2], pq_q[kMaxN / 2];
+    __shared__ double wgt[kMaxN];
+    __shared__ int s_rot;
+    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nblk = b.nblk;
+    IalmWin &st = b.win[w];
+    if (st.done) return;
+
+    if (k >= 1) {
+        double acc = 0.0;
+        for (int i = tid; i < nblk; i += 256) acc += b.zzpart[(int64_t)w * nblk + i];
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = 128; s; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double ratio = sqrt(red[0]) / st.dnorm;            // :297
+        if (ratio < tol || k >= maxiter) {
+            if (tid == 0) { st.iter = k; st.done = 1; atomicSub(b.active, 1); }
+            return;
+        }
+    }
+    IalmScal cur = st.nxt, nxt;
+    nxt.mu = cur.mu * 1.5;                                       // :295 (min(mu*rho, mu*1e7) == mu*rho)
+    nxt.inv_mu = 1.0 / nxt.mu;
+    nxt.thr = lmbda / nxt.mu;
+    __syncthreads();
+    if (tid == 0) { st.cur = cur; st.nxt = nxt; st.iter = k; }
+
+    // deterministic reduction of the per-block Gram partials
+    const double *gp = b.gpart + (int64_t)w * nblk * n * n;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        double acc = 0.0;
+        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + idx];
+        const int i = idx / n, j = idx % n;
+        G[i * kJac + j] = acc;
+        V[i * kJac + j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // cyclic Jacobi, round-robin ordering: m/2 disjoint rotations per round
+    const int m = n + (n & 1), half = m / 2;
+    int sweeps = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < m - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                round_robin_pair(m, r, tid, p, q);
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double gpq = G[p * kJac + q], gpp = G[p * kJac + p], gqq = G[q * kJac + q];
+                    if (gpq != 0.0 && fabs(gpq) > 1e-15 * sqrt(fabs(gpp * gqq))) {
+                        const double tau = (gqq - gpp) / (2.0 * gpq);
+                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + tt * tt);
+                        s = tt * c;
+                        s_rot = 1;
+                    }
+                }
+                pq_p[tid] = p; pq_q[tid] = q; cs_c[tid] = c; cs_s[tid] = s;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < n * half; idx += 256) {          // G <- G J, V <- V J
+                const int i = idx / half, kk = idx % half;
+                const double s = cs_s[kk];
+                if (s == 0.0) continue;
+                const double c = cs_c[kk];
+                const int p = pq_p[kk], q = pq_q[kk];
+                const double gp_ = G[i * kJac + p], gq_ = G[i * kJac + q];
+                G[i * kJac + p] = c * gp_ - s * gq_;
+                G[i * kJac + q] = s * gp_ + c * gq_;
+                const double vp = V[i * kJac + p], vq = V[i * kJac + q];
+                V[i * kJac + p] = c * vp - s * vq;
+                V[i * kJac + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < n * half; idx += 256) {          // G <- J^T G
+                const int j = idx % n, kk = idx / n;
+                const double s = cs_s[kk];
+                if (s == 0.0) continue;
+                const double c = cs_c[kk];
+                const int p = pq_p[kk], q = pq_q[kk];
+                const double gp_ = G[p * kJac + j], gq_ = G[q * kJac + j];
+                G[p * kJac + j] = c * gp_ - s * gq_;
+                G[q * kJac + j] = s * gp_ + c * gq_;
+            }
+            __syncthreads();
+        }
+        ++sweeps;
+        const int rot = s_rot;
+        __syncthreads();
+        if (!rot) break;
+    }
+    // G^(-1/2) = V diag(lambda^-1/2) V^T; zero (null-frame) directions get weight 0
+    if (tid < 64) {
+        double lam = tid < n ? G[tid * kJac + tid] : 0.0;
+        double lmax = lam;
+        for (int off = 32; off; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+        if (tid < n) wgt[tid] = lam > 1e-13 * lmax ? 1.0 / sqrt(lam) : 0.0;
+    }
+    __syncthreads();
+    double *Bm = b.Bm + (int64_t)w * n * n;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        double acc = 0.0;
+        for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
+        Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * acc;
+    }
+    if (tid == 0) st.sweeps = sweeps;
+}
+
+// planes [nwin][n][P] -> reference layout [nwin][P][n]
+__global__ void k_planes_to_pn(const double *__restrict__ planes, double *__restrict__ out, int n, int P)
+{
+    const int w = blockIdx.y;
+    const int64_t total = (int64_t)n * P;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i / n), j = (int)(i % n);
+    out[(int64_t)w * total + i] = planes[(int64_t)w * total + (int64_t)j * P + p];
+}
+
+__global__ void k_rpca_epilogue(const double *__restrict__ E, int64_t count, uint8_t *__restrict__ S)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        S[i] = sparse_u8(E[i]);
+}
+
+// ---------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------
+int ialm_pass_nblk(int variant, int n, int P, int nwin)
+{
+    (void)variant; (void)n;
+    const int ntiles = (P + 63) / 64;
+    // enough blocks to fill 256 CUs a few times over, few enough that the Gram partial
+    // slabs stay small next to the 34 B/element stream
+    int per_win = (256 * 8 + nwin - 1) / nwin;
+    if (per_win < 4) per_win = 4;
+    if (per_win > 128) per_win = 128;
+    if (per_win > ntiles) per_win = ntiles;
+    return per_win;
+}
+
+void launch_ialm_stats(hipStream_t s, const IalmBuffers &b)
+{
+    const int64_t per_win = (int64_t)b.n * b.P;
+    int bx = (int)((per_win + 256 * 16 - 1) / (256 * 16));
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_ialm_stats, dim3(bx, b.nwin), dim3(256), 0, s, b.X, b.win, per_win);
+}
+
+void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda)
+{
+    hipLaunchKernelGGL(k_ialm_init, dim3((b.nwin + 63) / 64), dim3(64), 0, s, b.win, b.active, b.nwin, lmbda);
+}
+
+template <int MODE, bool WE>
+static void launch_v1(hipStream_t s, const IalmBuffers &b)
+{
+    const int n8 = (b.n + 7) & ~7;
+    const size_t lds = (size_t)2 * n8 * kLdsRow * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v1<MODE, WE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxN * kLdsRow * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_ialm_pass_v1<MODE, WE>), dim3(b.nblk, b.nwin), dim3(64), lds, s, b);
+}
+
+void launch_ialm_pass_v2(hipStream_t s, const IalmBuffers &b, int mode);   // ialm_mfma.hip
+bool ialm_v2_supported(int n);
+
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant)
+{
+    if (variant == 2) { launch_ialm_pass_v2(s, b, mode); return; }
+    const bool we = b.E != nullptr;
+    if (mode == 0) launch_v1<0, false>(s, b);
+    else if (mode == 1) { if (we) launch_v1<1, true>(s, b); else launch_v1<1, false>(s, b); }
+    else { if (we) launch_v1<2, true>(s, b); else launch_v1<2, false>(s, b); }
+}
+
+void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter)
+{
+    hipLaunchKernelGGL(k_ialm_small, dim3(b.nwin), dim3(256), 0, s, b, k, lmbda, tol, maxiter);
+}
+
+void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P)
+{
+    const int64_t total = (int64_t)n * P;
+    hipLaunchKernelGGL(k_planes_to_pn, dim3((unsigned)((total + 255) / 256), nwin), dim3(256), 0, s, planes, out, n, P);
+}
+
+void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S)
+{
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_rpca_epilogue, dim3((unsigned)blocks), dim3(256), 0, s, E, count, S);
+}
+
+}  // namespace swk

@@ -1,0 +1,591 @@
+// C ABI of libswk.so (include/swk.h): context, workspaces, stage orchestration.
+// Host side only; every kernel lives in ialm*.hip / filters.hip / ccl.hip.
+#include "swk_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace swk;
+
+namespace {
+
+std::string g_create_error;
+
+enum Slot {
+    SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
+    SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
+    SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
+    SL_TAPDR, SL_TAPDC, SL_COUNT
+};
+
+struct EventPair { hipEvent_t a, b; int fam; };
+
+}  // namespace
+
+struct swk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    void *slot[SL_COUNT] = {nullptr};
+    size_t slot_bytes[SL_COUNT] = {0};
+    int *h_active = nullptr;             // pinned
+    // bilateral tables currently on the device
+    int bil_d = -1; double bil_sc = -1, bil_ss = -1;
+    BilateralTables bil{};
+    // profiling
+    bool prof_on = false;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[SWK_K_COUNT] = {0};
+    int64_t prof_n[SWK_K_COUNT] = {0};
+    int64_t window_iters = 0;
+    int ialm_variant = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            char buf_[512];                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = buf_;                                                                 \
+            return SWK_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+int fail(swk_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int need(swk_ctx *ctx, Slot s, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (ctx->slot_bytes[s] < bytes) {
+        if (ctx->slot[s]) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->slot[s])); }
+        ctx->slot[s] = nullptr;
+        ctx->slot_bytes[s] = 0;
+        hipError_t e = hipMalloc(&ctx->slot[s], bytes);
+        if (e != hipSuccess) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            ctx->err = buf;
+            return SWK_ERR_NOMEM;
+        }
+        ctx->slot_bytes[s] = bytes;
+    }
+    *out = ctx->slot[s];
+    return SWK_OK;
+}
+
+#define NEED(ctx, slot, bytes, ptr)                                          \
+    do { void *p_; int rc_ = need(ctx, slot, bytes, &p_); if (rc_) return rc_; ptr = (decltype(ptr))p_; } while (0)
+
+// ---- profiling --------------------------------------------------------------------
+hipEvent_t take_event(swk_ctx *ctx)
+{
+    if (!ctx->pool.empty()) { hipEvent_t e = ctx->pool.back(); ctx->pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {
+    swk_ctx *ctx; int fam; hipEvent_t a{}, b{};
+    Timed(swk_ctx *c, int f) : ctx(c), fam(f)
+    {
+        if (ctx->prof_on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, ctx->stream); }
+    }
+    ~Timed()
+    {
+        if (ctx->prof_on) { (void)hipEventRecord(b, ctx->stream); ctx->pending.push_back({a, b, fam}); }
+    }
+};
+
+void drain_prof(swk_ctx *ctx)
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { ctx->prof_ms[p.fam] += ms; ctx->prof_n[p.fam] += 1; }
+        ctx->pool.push_back(p.a);
+        ctx->pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+int sync(swk_ctx *ctx)
+{
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    drain_prof(ctx);
+    return SWK_OK;
+}
+
+// ---- bilateral weight tables (OpenCV 4.1.0 bilateralFilter_8u set-up, host side) ----
+int ensure_bilateral(swk_ctx *ctx, int d, double sigma_color, double sigma_space)
+{
+    if (ctx->bil_d == d && ctx->bil_sc == sigma_color && ctx->bil_ss == sigma_space) return SWK_OK;
+    double sc = sigma_color <= 0 ? 1 : sigma_color, ss = sigma_space <= 0 ? 1 : sigma_space;
+    const double gc = -0.5 / (sc * sc), gs = -0.5 / (ss * ss);
+    int radius = d <= 0 ? (int)lrint(ss * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    if (radius > 4) return fail(ctx, SWK_ERR_ARG, "bilateral diameter > 9 is not supported");
+    float cw[256], sw[81];
+    int8_t dr[81], dc[81];
+    for (int i = 0; i < 256; ++i) cw[i] = (float)exp((double)(i * i) * gc);
+    int k = 0;
+    for (int i = -radius; i <= radius; ++i)
+        for (int j = -radius; j <= radius; ++j) {
+            const double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            sw[k] = (float)exp(r * r * gs);
+            dr[k] = (int8_t)i; dc[k] = (int8_t)j;
+            ++k;
+        }
+    NEED(ctx, SL_COLORW, sizeof cw, ctx->bil.color_w);
+    NEED(ctx, SL_SPACEW, sizeof sw, ctx->bil.space_w);
+    NEED(ctx, SL_TAPDR, sizeof dr, ctx->bil.tap_dr);
+    NEED(ctx, SL_TAPDC, sizeof dc, ctx->bil.tap_dc);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->bil.color_w, cw, sizeof cw, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->bil.space_w, sw, sizeof(float) * k, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->bil.tap_dr, dr, k, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->bil.tap_dc, dc, k, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // cw/sw live on this stack frame
+    ctx->bil.maxk = k;
+    ctx->bil.radius = radius;
+    ctx->bil_d = d; ctx->bil_sc = sigma_color; ctx->bil_ss = sigma_space;
+    return SWK_OK;
+}
+
+int ensure_ccl(swk_ctx *ctx, int F, int H, int W, CclBuffers *b)
+{
+    b->Pp = (int)ccl_padded(H, W);
+    b->words = (int)ccl_words(H, W);
+    NEED(ctx, SL_PARENT, (size_t)F * b->Pp * 4, b->parent);
+    NEED(ctx, SL_ROOTBITS, (size_t)F * b->words * 4, b->rootbits);
+    NEED(ctx, SL_WORDPREFIX, (size_t)F * b->words * 4, b->wordprefix);
+    NEED(ctx, SL_NCOMP, (size_t)F * 4, b->ncomp);
+    NEED(ctx, SL_TABLE, (size_t)F * 256 * 8 * 4, b->table);
+    NEED(ctx, SL_SUMS, (size_t)F * 256 * 2 * 8, b->sums);
+    return SWK_OK;
+}
+
+// ---- IALM driver ----------------------------------------------------------------------
+int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmbda, double tol, int maxiter,
+             bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/)
+{
+    if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
+    IalmBuffers b{};
+    b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
+    int variant = ctx->ialm_variant;
+    if (variant == 0) variant = 1;
+    b.nblk = ialm_pass_nblk(variant, n, P, nwin);
+    const size_t elems = (size_t)nwin * n * P;
+    NEED(ctx, SL_A, elems * 8, b.A);
+    NEED(ctx, SL_Y, elems * 8, b.Y);
+    if (want_E) NEED(ctx, SL_E, elems * 8, b.E);
+    NEED(ctx, SL_BM, (size_t)nwin * n * n * 8, b.Bm);
+    NEED(ctx, SL_VPREV, (size_t)nwin * n * n * 8, b.Vprev);
+    NEED(ctx, SL_GPART, (size_t)nwin * b.nblk * n * n * 8, b.gpart);
+    NEED(ctx, SL_ZZPART, (size_t)nwin * b.nblk * 8, b.zzpart);
+    NEED(ctx, SL_WIN, (size_t)nwin * sizeof(IalmWin), b.win);
+    NEED(ctx, SL_ACTIVE, 16, b.active);
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(b.win, 0, (size_t)nwin * sizeof(IalmWin), s));
+    HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16, s));
+    HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
+    // a window that stops before writing A (all-zero input) must still read back zeros
+    HIPCHK(ctx, hipMemsetAsync(b.A, 0, elems * 8, s));
+    if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, elems * 8, s));
+    { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, b); launch_ialm_init(s, b, lmbda); }
+    { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, b, 0, variant); }
+    { Timed t(ctx, SWK_K_IALM_SMALL); launch_ialm_small(s, b, 0, lmbda, tol, maxiter); }
+    int active = nwin;
+    for (int k = 1; k <= maxiter; ++k) {
+        { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, b, k == 1 ? 1 : 2, variant); }
+        { Timed t(ctx, SWK_K_IALM_SMALL); launch_ialm_small(s, b, k, lmbda, tol, maxiter); }
+        ctx->window_iters += active;
+        if (k >= 6 || ctx->prof_on || k == maxiter) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, b.active, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+            active = *ctx->h_active;
+            if (active <= 0) break;
+        }
+    }
+    if (h_iters || d_iters) {
+        // iteration counts live in the per-window state structs; gather them
+        std::vector<IalmWin> hw(nwin);
+        HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        std::vector<int32_t> it(nwin);
+        for (int w = 0; w < nwin; ++w) it[w] = hw[w].iter;
+        if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
+        if (d_iters) {
+            HIPCHK(ctx, hipMemcpyAsync(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+        }
+    }
+    return SWK_OK;
+}
+
+int copy_out(swk_ctx *ctx, void *dst, const void *src, size_t bytes, int mem)
+{
+    if (!dst || dst == src) return SWK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, mem == SWK_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                               ctx->stream));
+    return SWK_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+#pragma GCC visibility push(default)
+extern "C" {
+
+int32_t swk_abi_version(void) { return SWK_ABI_VERSION; }
+
+void swk_params_default(swk_params *p)
+{
+    memset(p, 0, sizeof *p);
+    p->lmbda = 0.01; p->tol = 0.001; p->maxiter = 100;
+    p->bil_d = 7; p->bil_sigma_color = 15.0; p->bil_sigma_space = 1.0; p->bil_fma = 0;
+    p->thresh = 15; p->open_kh = 3; p->open_kw = 3;
+    p->connectivity = 8; p->label_order = SWK_ORDER_BLOCK2X2; p->gray_mode = SWK_GRAY_Q14;
+}
+
+const char *swk_last_error(const swk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32_t max_Hc, int32_t max_Wc, swk_ctx **out)
+{
+    if (!out) return SWK_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        g_create_error = "no HIP device visible: libswk has no CPU fallback";
+        return SWK_ERR_NOGPU;
+    }
+    if (device < 0 || device >= count) { g_create_error = "device index out of range"; return SWK_ERR_ARG; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return SWK_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", libswk is built for gfx950 (MI355X) only";
+        return SWK_ERR_NOGPU;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SWK_ERR_HIP; }
+    swk_ctx *ctx = new swk_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_active, 64, hipHostMallocDefault) != hipSuccess) {
+        g_create_error = "stream / pinned memory creation failed";
+        delete ctx;
+        return SWK_ERR_HIP;
+    }
+    // pre-size the big workspaces so the first batch does not pay for hipMalloc
+    if (max_windows > 0 && max_n > 0 && max_Hc > 0 && max_Wc > 0) {
+        const size_t elems = (size_t)max_windows * max_n * max_Hc * max_Wc;
+        void *p;
+        int rc = 0;
+        rc = rc ? rc : need(ctx, SL_X, elems, &p);
+        rc = rc ? rc : need(ctx, SL_S, elems, &p);
+        rc = rc ? rc : need(ctx, SL_OPEN, elems, &p);
+        rc = rc ? rc : need(ctx, SL_LAB8, elems, &p);
+        rc = rc ? rc : need(ctx, SL_A, elems * 8, &p);
+        rc = rc ? rc : need(ctx, SL_Y, elems * 8, &p);
+        if (rc) { g_create_error = ctx->err; swk_ctx_destroy(ctx); return rc; }
+    }
+    *out = ctx;
+    return SWK_OK;
+}
+
+void swk_ctx_destroy(swk_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drain_prof(ctx);
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < SL_COUNT; ++i)
+        if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
+    if (ctx->h_active) (void)hipHostFree(ctx->h_active);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int64_t swk_ctx_device_bytes(const swk_ctx *ctx)
+{
+    int64_t t = 0;
+    if (ctx) for (int i = 0; i < SL_COUNT; ++i) t += (int64_t)ctx->slot_bytes[i];
+    return t;
+}
+
+int32_t swk_prof_enable(swk_ctx *ctx, int32_t on) { if (!ctx) return SWK_ERR_ARG; ctx->prof_on = on != 0; return SWK_OK; }
+int32_t swk_prof_reset(swk_ctx *ctx)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    memset(ctx->prof_ms, 0, sizeof ctx->prof_ms);
+    memset(ctx->prof_n, 0, sizeof ctx->prof_n);
+    ctx->window_iters = 0;
+    return SWK_OK;
+}
+int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *launches)
+{
+    if (!ctx || family < 0 || family >= SWK_K_COUNT) return SWK_ERR_ARG;
+    if (ms_total) *ms_total = ctx->prof_ms[family];
+    if (launches) *launches = ctx->prof_n[family];
+    return SWK_OK;
+}
+int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters)
+{
+    if (!ctx || !window_iters) return SWK_ERR_ARG;
+    *window_iters = ctx->window_iters;
+    return SWK_OK;
+}
+int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
+{
+    if (!ctx || variant < 0 || variant > 2) return SWK_ERR_ARG;
+    ctx->ialm_variant = variant;
+    return SWK_OK;
+}
+
+// -------------------------------------------------------------------------------------
+int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, swk_output *out)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    if (!in || !p || !out || !in->frames) return fail(ctx, SWK_ERR_ARG, "null argument");
+    if (in->nwin < 1 || in->n < 1 || in->Hc < 1 || in->Wc < 1) return fail(ctx, SWK_ERR_ARG, "empty batch");
+    if (in->channels != 1 && in->channels != 3) return fail(ctx, SWK_ERR_ARG, "channels must be 1 or 3");
+    if (in->n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be <= 64");
+    if (p->open_kh != 3 || p->open_kw != 3) return fail(ctx, SWK_ERR_ARG, "only the (3,3) opening window is implemented");
+    if (p->connectivity != 4 && p->connectivity != 8) return fail(ctx, SWK_ERR_ARG, "connectivity must be 4 or 8");
+    if (p->bil_d / 2 != 3) return fail(ctx, SWK_ERR_ARG, "the fused filter kernel implements bilateral d=7 (radius 3) only");
+    if (out->segs && (out->seg_cap < 1 || out->seg_cap > 255)) return fail(ctx, SWK_ERR_ARG, "seg_cap must be in 1..255");
+    if (in->Hc < 4 || in->Wc < 4) return fail(ctx, SWK_ERR_ARG, "ROI must be at least 4x4");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int F = in->nwin * in->n, H = in->Hc, W = in->Wc, P = H * W;
+    const size_t plane = (size_t)F * P;
+    const bool dev_out = out->mem == SWK_MEM_DEVICE;
+    int rc;
+
+    // ---- input ----
+    const uint8_t *dframes = in->frames;
+    int64_t fs = in->frame_stride, rs = in->row_stride;
+    int x0 = in->x0, y0 = in->y0;
+    if (in->mem == SWK_MEM_HOST) {
+        uint8_t *roi;
+        NEED(ctx, SL_ROI, plane * in->channels, roi);
+        Timed t(ctx, SWK_K_COPY);
+        const size_t rowb = (size_t)W * in->channels;
+        for (int f = 0; f < F; ++f)
+            HIPCHK(ctx, hipMemcpy2DAsync(roi + (size_t)f * P * in->channels, rowb,
+                                         in->frames + (int64_t)f * fs + (int64_t)y0 * rs + (int64_t)x0 * in->channels, (size_t)rs,
+                                         rowb, H, hipMemcpyHostToDevice, s));
+        dframes = roi; fs = (int64_t)P * in->channels; rs = (int64_t)rowb; x0 = 0; y0 = 0;
+    }
+    // ---- stage buffers (caller's device buffers are written in place) ----
+    uint8_t *dX, *dS, *dBil = nullptr, *dThr = nullptr, *dOpen, *dLab;
+    if (dev_out && out->gray) dX = out->gray; else NEED(ctx, SL_X, plane, dX);
+    if (dev_out && out->rpca) dS = out->rpca; else NEED(ctx, SL_S, plane, dS);
+    if (out->bilateral) { if (dev_out) dBil = out->bilateral; else NEED(ctx, SL_BIL, plane, dBil); }
+    if (out->thresh) { if (dev_out) dThr = out->thresh; else NEED(ctx, SL_THR, plane, dThr); }
+    if (dev_out && out->opened) dOpen = out->opened; else NEED(ctx, SL_OPEN, plane, dOpen);
+    if (dev_out && out->labels) dLab = out->labels; else NEED(ctx, SL_LAB8, plane, dLab);
+
+    { Timed t(ctx, SWK_K_GRAY); launch_gray(s, dframes, in->channels, fs, rs, x0, y0, F, H, W, p->gray_mode, dX); }
+
+    rc = run_ialm(ctx, dX, in->nwin, in->n, P, p->lmbda, p->tol, p->maxiter, out->E != nullptr, dS,
+                  (!dev_out) ? out->iters : nullptr, dev_out ? out->iters : nullptr);
+    if (rc) return rc;
+
+    rc = ensure_bilateral(ctx, p->bil_d, p->bil_sigma_color, p->bil_sigma_space);
+    if (rc) return rc;
+    { Timed t(ctx, SWK_K_FILTER); launch_filter_fused(s, dS, F, H, W, ctx->bil, p->bil_fma, p->thresh, dBil, dThr, dOpen); }
+
+    CclBuffers cb{};
+    rc = ensure_ccl(ctx, F, H, W, &cb);
+    if (rc) return rc;
+    { Timed t(ctx, SWK_K_CCL); launch_ccl(s, dOpen, F, H, W, p->connectivity, p->label_order, cb, nullptr, dLab); }
+
+    if (out->segs || out->nseg) {
+        const int cap = out->segs ? out->seg_cap : 1;
+        swk_segment *dsegs; int32_t *dnseg;
+        if (dev_out && out->segs) dsegs = out->segs; else NEED(ctx, SL_SEGS, (size_t)F * cap * sizeof(swk_segment), dsegs);
+        if (dev_out && out->nseg) dnseg = out->nseg; else NEED(ctx, SL_NSEG, (size_t)F * 4, dnseg);
+        HIPCHK(ctx, hipMemsetAsync(dsegs, 0, (size_t)F * cap * sizeof(swk_segment), s));
+        { Timed t(ctx, SWK_K_PROPS); launch_regionprops(s, dLab, F, H, W, cb, cap, dsegs, dnseg); }
+        if (!dev_out) {
+            rc = copy_out(ctx, out->segs, dsegs, (size_t)F * cap * sizeof(swk_segment), out->mem); if (rc) return rc;
+            rc = copy_out(ctx, out->nseg, dnseg, (size_t)F * 4, out->mem); if (rc) return rc;
+        }
+    }
+    // ---- float outputs in the reference's (pixels, frames) layout ----
+    if (out->A || out->E) {
+        const size_t elems = (size_t)in->nwin * in->n * P;
+        for (int which = 0; which < 2; ++which) {
+            double *dst = which == 0 ? out->A : out->E;
+            if (!dst) continue;
+            const double *planes = (const double *)ctx->slot[which == 0 ? SL_A : SL_E];
+            double *pn;
+            if (dev_out) pn = dst; else NEED(ctx, SL_PN, elems * 8, pn);
+            { Timed t(ctx, SWK_K_COPY); launch_planes_to_pn(s, planes, pn, in->nwin, in->n, P); }
+            if (!dev_out) { rc = copy_out(ctx, dst, pn, elems * 8, out->mem); if (rc) return rc; HIPCHK(ctx, hipStreamSynchronize(s)); }
+        }
+    }
+    if (!dev_out) {
+        Timed t(ctx, SWK_K_COPY);
+        rc = copy_out(ctx, out->gray, dX, plane, out->mem); if (rc) return rc;
+        rc = copy_out(ctx, out->rpca, dS, plane, out->mem); if (rc) return rc;
+        rc = copy_out(ctx, out->bilateral, dBil, plane, out->mem); if (rc) return rc;
+        rc = copy_out(ctx, out->thresh, dThr, plane, out->mem); if (rc) return rc;
+        rc = copy_out(ctx, out->opened, dOpen, plane, out->mem); if (rc) return rc;
+        rc = copy_out(ctx, out->labels, dLab, plane, out->mem); if (rc) return rc;
+    }
+    return sync(ctx);
+}
+
+// ---- stage-level entry points (host buffers) ----------------------------------------
+int32_t swk_bgr2gray(swk_ctx *ctx, const uint8_t *bgr, int32_t count, int32_t H, int32_t W, int32_t gray_mode, uint8_t *gray)
+{
+    if (!ctx || !bgr || !gray || count < 1 || H < 1 || W < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din, *dout;
+    NEED(ctx, SL_TMP_IN, px * 3, din);
+    NEED(ctx, SL_TMP_OUT, px, dout);
+    HIPCHK(ctx, hipMemcpyAsync(din, bgr, px * 3, hipMemcpyHostToDevice, ctx->stream));
+    launch_gray(ctx->stream, din, 3, (int64_t)H * W * 3, (int64_t)W * 3, 0, 0, count, H, W, gray_mode, dout);
+    HIPCHK(ctx, hipMemcpyAsync(gray, dout, px, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P, double lmbda, double tol, int32_t maxiter,
+                 double *A, double *E, int32_t *iters)
+{
+    if (!ctx || !planes || n < 1 || P < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t elems = (size_t)n * P;
+    uint8_t *dX, *dS;
+    NEED(ctx, SL_X, elems, dX);
+    NEED(ctx, SL_S, elems, dS);
+    HIPCHK(ctx, hipMemcpyAsync(dX, planes, elems, hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_ialm(ctx, dX, 1, n, P, lmbda, tol, maxiter, E != nullptr, dS, iters, nullptr);
+    if (rc) return rc;
+    for (int which = 0; which < 2; ++which) {
+        double *dst = which == 0 ? A : E;
+        if (!dst) continue;
+        double *pn;
+        NEED(ctx, SL_PN, elems * 8, pn);
+        launch_planes_to_pn(ctx->stream, (const double *)ctx->slot[which == 0 ? SL_A : SL_E], pn, 1, n, P);
+        HIPCHK(ctx, hipMemcpyAsync(dst, pn, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return sync(ctx);
+}
+
+int32_t swk_rpca_epilogue(swk_ctx *ctx, const double *E, int64_t count, uint8_t *S)
+{
+    if (!ctx || !E || !S || count < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *din; uint8_t *dout;
+    NEED(ctx, SL_PN, (size_t)count * 8, din);
+    NEED(ctx, SL_TMP_OUT, (size_t)count, dout);
+    HIPCHK(ctx, hipMemcpyAsync(din, E, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_rpca_epilogue(ctx->stream, din, count, dout);
+    HIPCHK(ctx, hipMemcpyAsync(S, dout, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_bilateral_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t d,
+                         double sigma_color, double sigma_space, int32_t use_fma, uint8_t *dst)
+{
+    if (!ctx || !src || !dst || count < 1 || H < 2 || W < 2) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_bilateral(ctx, d, sigma_color, sigma_space);
+    if (rc) return rc;
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din, *dout;
+    NEED(ctx, SL_TMP_IN, px, din);
+    NEED(ctx, SL_TMP_OUT, px, dout);
+    HIPCHK(ctx, hipMemcpyAsync(din, src, px, hipMemcpyHostToDevice, ctx->stream));
+    launch_bilateral(ctx->stream, din, count, H, W, ctx->bil, use_fma, dout);
+    HIPCHK(ctx, hipMemcpyAsync(dst, dout, px, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_thresh_tozero_u8(swk_ctx *ctx, const uint8_t *src, int64_t count, int32_t thresh, uint8_t *dst)
+{
+    if (!ctx || !src || !dst || count < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    uint8_t *din, *dout;
+    NEED(ctx, SL_TMP_IN, (size_t)count, din);
+    NEED(ctx, SL_TMP_OUT, (size_t)count, dout);
+    HIPCHK(ctx, hipMemcpyAsync(din, src, (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    launch_thresh(ctx->stream, din, count, thresh, dout);
+    HIPCHK(ctx, hipMemcpyAsync(dst, dout, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_grey_open3x3_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, uint8_t *dst)
+{
+    if (!ctx || !src || !dst || count < 1 || H < 1 || W < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din, *dout;
+    NEED(ctx, SL_TMP_IN, px, din);
+    NEED(ctx, SL_TMP_OUT, px, dout);
+    HIPCHK(ctx, hipMemcpyAsync(din, src, px, hipMemcpyHostToDevice, ctx->stream));
+    launch_open3x3(ctx->stream, din, count, H, W, dout);
+    HIPCHK(ctx, hipMemcpyAsync(dst, dout, px, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t connectivity,
+                   int32_t label_order, int32_t *labels, int32_t *ncomp)
+{
+    if (!ctx || !src || count < 1 || H < 1 || W < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    if (connectivity != 4 && connectivity != 8) return fail(ctx, SWK_ERR_ARG, "connectivity must be 4 or 8");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din; int32_t *dlab;
+    NEED(ctx, SL_TMP_IN, px, din);
+    NEED(ctx, SL_LAB32, px * 4, dlab);
+    CclBuffers cb{};
+    int rc = ensure_ccl(ctx, count, H, W, &cb);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(din, src, px, hipMemcpyHostToDevice, ctx->stream));
+    launch_ccl(ctx->stream, din, count, H, W, connectivity, label_order, cb, dlab, nullptr);
+    if (labels) HIPCHK(ctx, hipMemcpyAsync(labels, dlab, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ncomp) HIPCHK(ctx, hipMemcpyAsync(ncomp, cb.ncomp, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, int32_t H, int32_t W, int32_t seg_cap,
+                           swk_segment *segs, int32_t *nseg)
+{
+    if (!ctx || !labels || !segs || !nseg || count < 1 || H < 1 || W < 1 || seg_cap < 1 || seg_cap > 255)
+        return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din; swk_segment *dsegs; int32_t *dnseg;
+    NEED(ctx, SL_TMP_IN, px, din);
+    NEED(ctx, SL_SEGS, (size_t)count * seg_cap * sizeof(swk_segment), dsegs);
+    NEED(ctx, SL_NSEG, (size_t)count * 4, dnseg);
+    CclBuffers cb{};
+    int rc = ensure_ccl(ctx, count, H, W, &cb);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(din, labels, px, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(dsegs, 0, (size_t)count * seg_cap * sizeof(swk_segment), ctx->stream));
+    launch_regionprops(ctx->stream, din, count, H, W, cb, seg_cap, dsegs, dnseg);
+    HIPCHK(ctx, hipMemcpyAsync(segs, dsegs, (size_t)count * seg_cap * sizeof(swk_segment), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(nseg, dnseg, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,83 @@
+// Internal declarations shared by the HIP translation units of libswk.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "swk.h"
+
+namespace swk {
+
+constexpr int kMaxN = 64;          // frames per window supported by the IALM kernels
+
+// Per-window scalar state of the IALM loop (device resident).
+struct IalmScal { double mu, inv_mu, thr; };
+struct IalmWin {
+    IalmScal cur;                  // mu of the iteration being finished (image_filtering.py:282-294)
+    IalmScal nxt;                  // mu of the iteration being started  (:295)
+    double dual_norm;              // :271
+    double dnorm;                  // :275
+    unsigned long long sumsq;      // exact sum of squares of the u8 window
+    unsigned int maxv;
+    int iter;                      // iterations completed
+    int done;
+    int sweeps;                    // Jacobi sweeps used by the last eigen solve (diagnostic)
+};
+
+struct IalmBuffers {
+    const uint8_t *X;              // [nwin][n][P]
+    double *A, *Y;                 // [nwin][n][P]
+    uint8_t *S;                    // [nwin][n][P]
+    double *E;                     // optional [nwin][n][P]
+    double *Bm;                    // [nwin][n][n]   I - W/mu
+    double *Vprev;                 // [nwin][n][n]   eigenvectors of the previous solve (warm start)
+    double *gpart;                 // [nwin][nblk][n][n]
+    double *zzpart;                // [nwin][nblk]
+    IalmWin *win;                  // [nwin]
+    int *active;                   // device counter of windows not yet converged
+    int nwin, n, P, nblk;
+};
+
+// ialm.hip
+void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
+void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant);
+void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter);
+void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P);
+void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S);
+int  ialm_pass_nblk(int variant, int n, int P, int nwin);
+
+// filters.hip
+struct BilateralTables {           // device copies of the weight tables
+    float *color_w;                // [256]
+    float *space_w;                // [maxk]
+    int8_t *tap_dr, *tap_dc;       // [maxk]
+    int maxk, radius;
+};
+void launch_gray(hipStream_t s, const uint8_t *frames, int channels, int64_t frame_stride, int64_t row_stride,
+                 int x0, int y0, int F, int H, int W, int gray_mode, uint8_t *out);
+void launch_bilateral(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
+                      int use_fma, uint8_t *dst);
+void launch_thresh(hipStream_t s, const uint8_t *src, int64_t count, int thresh, uint8_t *dst);
+void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint8_t *dst);
+// fused bilateral (radius 3) + to-zero threshold + 3x3 opening; optional intermediates
+void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
+                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out);
+
+// ccl.hip
+struct CclBuffers {
+    int32_t *parent;               // [F][Pp] in the id space chosen by label_order
+    uint32_t *rootbits;            // [F][words]
+    int32_t *wordprefix;           // [F][words]
+    int32_t *ncomp;                // [F]
+    int32_t *table;                // [F][256][8] region accumulators (ints)
+    unsigned long long *sums;      // [F][256][2] sum_r, sum_c
+    int words;                     // per frame
+    int Pp;                        // padded id-space size per frame
+};
+void launch_ccl(hipStream_t s, const uint8_t *src, int F, int H, int W, int connectivity, int order,
+                const CclBuffers &b, int32_t *labels32 /*optional*/, uint8_t *labels8 /*optional*/);
+void launch_regionprops(hipStream_t s, const uint8_t *labels8, int F, int H, int W, const CclBuffers &b,
+                        int seg_cap, swk_segment *segs, int32_t *nseg);
+size_t ccl_words(int H, int W);
+size_t ccl_padded(int H, int W);
+
+}  // namespace swk

@@ -1,0 +1,167 @@
+"""Drop-in for the preprocessing + segmentation sections of the reference's
+swiftwatcher/image_filtering.py (lines 188-369): same function names, argument meaning and
+return types, every pixel operation running as a HIP kernel on the MI355X through
+libswk.so (ctypes, swiftwatcher_amd/_lib.py).  No OpenCV / SciPy / scikit-image involved
+and no CPU fallback: without the GPU library these functions raise SwkError.
+
+The ROI-mask section of the reference file (generate_roi_mask and friends, lines 99-180)
+runs once per video, feeds the tracker, and is out of scope.
+"""
+import math
+
+import numpy as np
+
+from . import _lib
+
+###############################################################################
+# crop geometry -- pure integer arithmetic, image_filtering.py:31-91
+###############################################################################
+
+
+def determine_chimney_extents(corners):
+    """image_filtering.py:78-91: (left, right, bottom) of the two chimney corners."""
+    left = min(corners[0][0], corners[1][0])
+    right = max(corners[0][0], corners[1][0])
+    bottom = max(corners[0][1], corners[1][1])
+    return left, right, bottom
+
+
+def generate_crop_region(corners):
+    """image_filtering.py:31-53: [(x0, y0), (x1, y1)], 1.25 x 0.625 chimney widths."""
+    left, right, bottom = determine_chimney_extents(corners)
+    width = right - left
+    return [(left - int(0.125 * width), bottom - int(0.5 * width)),
+            (right + int(0.125 * width), bottom + int(0.125 * width))]
+
+
+def generate_roi_crop_region(corners):
+    """image_filtering.py:56-75."""
+    left, right, bottom = determine_chimney_extents(corners)
+    width = right - left
+    return [(int(left + 0.025 * width), int(bottom - 0.25 * width)),
+            (int(right - 0.025 * width), int(bottom))]
+
+
+def crop_frame(frame, crop_region):
+    """image_filtering.py:199-203: a view, like the reference."""
+    return frame[crop_region[0][1]:crop_region[1][1], crop_region[0][0]:crop_region[1][0]]
+
+
+###############################################################################
+# stages -- each one a HIP kernel behind the C ABI
+###############################################################################
+
+
+def _ctx():
+    return _lib.default_context()
+
+
+def convert_grayscale(frame, gray_mode=_lib.GRAY_Q14):
+    """image_filtering.py:188-196.  3-channel BGR -> gray with OpenCV 4.1.0's fixed-point
+    weights; a 2-D frame passes through unchanged (:193-194)."""
+    if frame.ndim == 2:
+        return frame
+    return _ctx().bgr2gray(frame, gray_mode)
+
+
+def inexact_augmented_lagrange_multiplier(X, lmbda=0.01, tol=0.001, maxiter=100, verbose=False):
+    """image_filtering.py:256-301.  X: (pixels, frames) uint8 matrix of column-vector images.
+    Returns (A, E) float64 (pixels, frames)."""
+    X = np.asarray(X)
+    if X.dtype != np.uint8:
+        raise TypeError("the HIP IALM takes the uint8 image matrix the reference passes (image_filtering.py:234-241)")
+    planes = np.ascontiguousarray(X.T)
+    A, E, it = _ctx().ialm(planes, lmbda, tol, maxiter, want_E=True)
+    if verbose:
+        print("Finished at iteration %d" % it)
+    return A, E
+
+
+def rpca(frame_list):
+    """image_filtering.py:220-253: list of n gray frames -> list of n uint8 sparse images."""
+    stack = np.ascontiguousarray(np.array(frame_list), np.uint8)
+    n, H, W = stack.shape
+    res = _ctx().batch_run(stack, 1, n, stages=("rpca",), seg_cap=1)
+    return [res["rpca"][i] for i in range(n)]
+
+
+def bilateral_blur(frame, d, sigmaColor, sigmaSpace, use_fma=False):
+    """image_filtering.py:304-307."""
+    return _ctx().bilateral_u8(frame, d, float(sigmaColor), float(sigmaSpace), use_fma)
+
+
+def thresh_to_zero(frame, thresh):
+    """image_filtering.py:310-316."""
+    return _ctx().thresh_tozero_u8(frame, int(thresh))
+
+
+def grayscale_opening(frame, SE):
+    """image_filtering.py:319-322.  Only the (3, 3) window the reference uses
+    (data_structures.py:202) is implemented on the GPU."""
+    if tuple(SE) != (3, 3):
+        raise NotImplementedError("grey opening is implemented for SE=(3, 3) only")
+    return _ctx().grey_open3x3_u8(frame)
+
+
+def cc_labeling(frame, connectivity=None, effective_connectivity=8, label_order=_lib.ORDER_BLOCK2X2):
+    """image_filtering.py:325-329.
+
+    The reference calls cv2.connectedComponents(frame, connectivity) with connectivity=4
+    (data_structures.py:206), but the binding's second positional parameter is `labels`, so
+    OpenCV runs its defaults: 8-connectivity, BBDT numbering.  To stay a drop-in the positional
+    `connectivity` is accepted and, like there, has no effect; use effective_connectivity /
+    label_order to choose something else.  Returns uint8 labels (wraps mod 256 like astype)."""
+    _, lab = _ctx().ccl_u8(frame, effective_connectivity, label_order)
+    return (lab & 0xff).astype(np.uint8)
+
+
+class RegionProps:
+    """The regionprops fields the rest of swiftwatcher reads (label, bbox, centroid, area)."""
+    __slots__ = ("label", "bbox", "centroid", "area")
+
+    def __init__(self, label, bbox, centroid, area):
+        self.label = label
+        self.bbox = bbox
+        self.centroid = centroid
+        self.area = area
+
+    def __repr__(self):
+        return "RegionProps(label=%d, bbox=%r, centroid=%r, area=%d)" % (self.label, self.bbox, self.centroid, self.area)
+
+
+def regionprops_from_records(records):
+    """swk_segment records -> RegionProps list.  The centroid is sum/area in float64, which is
+    bit-identical to skimage's coords.mean(axis=0)."""
+    out = []
+    for s in records:
+        area = int(s["area"])
+        out.append(RegionProps(int(s["label"]), (int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"])),
+                               (int(s["sum_r"]) / area, int(s["sum_c"]) / area), area))
+    return out
+
+
+def get_segment_properties(frame):
+    """image_filtering.py:332-335: one RegionProps per distinct nonzero label, ascending."""
+    segs, _ = _ctx().regionprops_u8(frame)
+    return regionprops_from_records(segs)
+
+
+def extract_segment_images(segments, frame, min_seg_size, crop_region):
+    """image_filtering.py:338-369: expand each bbox to at least min_seg_size (floor/ceil split),
+    translate by the crop origin and slice the FULL frame (views, no clamping -- same silent
+    mis-slicing as the reference when the box leaves the frame)."""
+    images = []
+    oy, ox = crop_region[0][1], crop_region[0][0]
+    for segment in segments:
+        r0, c0, r1, c1 = segment.bbox
+        h, w = r1 - r0, c1 - c0
+        if h < min_seg_size[0]:
+            d = min_seg_size[0] - h
+            r0 -= math.floor(d / 2)
+            r1 += math.ceil(d / 2)
+        if w < min_seg_size[1]:
+            d = min_seg_size[1] - w
+            c0 -= math.floor(d / 2)
+            c1 += math.ceil(d / 2)
+        images.append(frame[r0 + oy:r1 + oy, c0 + ox:c1 + ox])
+    return images

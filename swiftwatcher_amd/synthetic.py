@@ -1,0 +1,101 @@
+"""Deterministic synthetic chimney scenes: vertical sky gradient with
+per-channel offsets, a dark textured chimney at the bottom of the ROI, i.i.d. Gaussian sensor
+noise on every pixel (keeps RPCA windows full rank) and dark elliptical "birds" in linear
+motion.  numpy version for tests (host arrays, any size); torch version for the benchmark
+(builds a multi-GB stream directly in HBM)."""
+import numpy as np
+
+P2 = dict(Hc=212, Wc=424, bird_len=(30, 50), bird_wid=(12, 20))     # w = 340 px chimney, 1080p
+P1 = dict(Hc=107, Wc=214, bird_len=(10, 15), bird_wid=(4, 7))       # w = 172 px chimney, 1080p
+P3 = dict(Hc=425, Wc=850, bird_len=(60, 100), bird_wid=(24, 40))    # 4K scale-up
+
+
+def _background(Hc, Wc):
+    yy = np.arange(Hc, dtype=np.float64)[:, None]
+    sky = 150.0 + 65.0 * yy / max(Hc - 1, 1)
+    base = np.repeat(sky, Wc, axis=1)
+    bgr = np.stack([base + 10.0, base, base - 10.0], axis=-1)
+    top = int(round(Hc * 0.8))
+    x0, x1 = int(round(Wc * 0.1)), int(round(Wc * 0.9))
+    return bgr, (top, x0, x1)
+
+
+def roi_window(seed, n, Hc, Wc, birds=12, bird_len=(30, 50), bird_wid=(12, 20), noise=2.5, null_frames=0):
+    """(n, Hc, Wc, 3) uint8 BGR ROI frames, queue order (index 0 = newest)."""
+    rng = np.random.default_rng(seed)
+    bgr, (top, x0, x1) = _background(Hc, Wc)
+    tex = rng.uniform(-8, 8, size=(Hc - top, x1 - x0))
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    pos = np.stack([rng.uniform(0, Hc * 0.75, birds), rng.uniform(0, Wc, birds)], 1)
+    speed = rng.uniform(5, 25, birds) * (Wc / 424.0)
+    heading = rng.uniform(0, 2 * np.pi, birds)
+    vel = np.stack([np.sin(heading), np.cos(heading)], 1) * speed[:, None]
+    length = rng.uniform(*bird_len, birds)
+    width = rng.uniform(*bird_wid, birds)
+    contrast = rng.uniform(40, 90, birds)
+    out = np.empty((n, Hc, Wc, 3), np.uint8)
+    for t in range(n):
+        f = bgr.copy()
+        f[top:, x0:x1, :] = 60.0 + tex[:, :, None]
+        age = n - 1 - t                      # index 0 is the newest frame
+        for b in range(birds):
+            cy = (pos[b, 0] + vel[b, 0] * age) % Hc
+            cx = (pos[b, 1] + vel[b, 1] * age) % Wc
+            ca, sa = np.cos(heading[b]), np.sin(heading[b])
+            u = (xx - cx) * ca + (yy - cy) * sa
+            v = -(xx - cx) * sa + (yy - cy) * ca
+            m = (u / (length[b] / 2)) ** 2 + (v / (width[b] / 2)) ** 2 <= 1.0
+            f[m] -= contrast[b]
+        f += rng.normal(0.0, noise, size=f.shape)
+        out[t] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    if null_frames:
+        out[:null_frames] = 0
+    return out
+
+
+def full_frames(seed, n, crop_region, frame_hw=(1080, 1920), **kw):
+    """Whole 1080p BGR frames whose crop_region holds roi_window(); the rest is flat sky."""
+    (x0, y0), (x1, y1) = crop_region
+    roi = roi_window(seed, n, y1 - y0, x1 - x0, **kw)
+    frames = np.full((n,) + tuple(frame_hw) + (3,), 128, np.uint8)
+    frames[:, y0:y1, x0:x1] = roi
+    return frames
+
+
+def roi_stream_torch(device, nframes, Hc, Wc, seed=20190816, birds=12, bird_len=(30, 50), bird_wid=(12, 20),
+                     noise=2.5, chunk=128):
+    """(nframes, Hc, Wc, 3) uint8 CUDA tensor built in HBM.  Each consecutive frame advances every
+    bird along its line; the scene statistics match roi_window()."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bgr_np, (top, x0, x1) = _background(Hc, Wc)
+    bgr = torch.tensor(bgr_np, device=device, dtype=torch.float32)
+    tex = (torch.rand((Hc - top, x1 - x0), generator=g, device=device) * 16.0 - 8.0)
+    bgr[top:, x0:x1, :] = 60.0 + tex[:, :, None]
+    yy = torch.arange(Hc, device=device, dtype=torch.float32)[None, None, :, None]
+    xx = torch.arange(Wc, device=device, dtype=torch.float32)[None, None, None, :]
+
+    def u(lo, hi):
+        return torch.rand(birds, generator=g, device=device) * (hi - lo) + lo
+
+    py, px = u(0, Hc * 0.75), u(0, Wc)
+    speed = u(5, 25) * (Wc / 424.0)
+    heading = u(0, 2 * np.pi)
+    vy, vx = torch.sin(heading) * speed, torch.cos(heading) * speed
+    length, width, contrast = u(*bird_len), u(*bird_wid), u(40, 90)
+    out = torch.empty((nframes, Hc, Wc, 3), dtype=torch.uint8, device=device)
+    for f0 in range(0, nframes, chunk):
+        fc = min(chunk, nframes - f0)
+        t = torch.arange(f0, f0 + fc, device=device, dtype=torch.float32)[:, None]
+        cy = ((py[None] + vy[None] * t) % Hc)[:, :, None, None]
+        cx = ((px[None] + vx[None] * t) % Wc)[:, :, None, None]
+        ca, sa = torch.cos(heading)[None, :, None, None], torch.sin(heading)[None, :, None, None]
+        uu = (xx - cx) * ca + (yy - cy) * sa
+        vv = -(xx - cx) * sa + (yy - cy) * ca
+        m = (uu / (length[None, :, None, None] / 2)) ** 2 + (vv / (width[None, :, None, None] / 2)) ** 2 <= 1.0
+        dark = (m.to(torch.float32) * contrast[None, :, None, None]).sum(1)          # (fc, Hc, Wc)
+        f = bgr[None] - dark[..., None]
+        f = f + torch.randn(f.shape, generator=g, device=device) * noise
+        out[f0:f0 + fc] = f.round().clamp(0, 255).to(torch.uint8)
+    return out

@@ -1,0 +1,121 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol
+include/swk.h declares (no compute calls without a GPU), struct layouts match, host logic
+(crop geometry, segment boxes, FrameQueue bookkeeping) behaves like the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from swiftwatcher_amd.csrc import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "swk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(swk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libswk.so does not export %s" % name
+    from swiftwatcher_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+    assert _lib.load().swk_abi_version() == 1
+
+
+def test_struct_layouts_and_defaults(built_lib):
+    import subprocess
+    import tempfile
+    from swiftwatcher_amd import _lib
+    # sizes as the C compiler lays out include/swk.h
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "swk.h"\nint main(){printf("%zu %zu %zu %zu", '
+                             'sizeof(swk_params), sizeof(swk_input), sizeof(swk_output), sizeof(swk_segment));}')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(d, "sz")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "sz")]).split()]
+    assert sizes == [ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.Input), ctypes.sizeof(_lib.Output),
+                     ctypes.sizeof(_lib.Segment)]
+    assert ctypes.sizeof(_lib.Segment) == 48
+    p = _lib.default_params()
+    # the reference's hard-coded literals
+    assert (p.lmbda, p.tol, p.maxiter) == (0.01, 0.001, 100)
+    assert (p.bil_d, p.bil_sigma_color, p.bil_sigma_space) == (7, 15.0, 1.0)
+    assert (p.thresh, p.open_kh, p.open_kw) == (15, 3, 3)
+    assert (p.connectivity, p.label_order, p.gray_mode) == (8, _lib.ORDER_BLOCK2X2, _lib.GRAY_Q14)
+    with pytest.raises(TypeError):
+        _lib.default_params(nonsense=1)
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    """There is no CPU fallback: without a gfx950 device a context cannot be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from swiftwatcher_amd import _lib
+    with pytest.raises(_lib.SwkError):
+        _lib.Context(0)
+    from swiftwatcher_amd import image_filtering as img
+    with pytest.raises(_lib.SwkError):
+        img.thresh_to_zero(np.zeros((4, 4), np.uint8), 15)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "swiftwatcher_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the CPU oracle", ""), "%s mentions the oracle" % f
+
+
+def test_crop_geometry_golden(golden_dir):
+    from swiftwatcher_amd import image_filtering as img
+    g = np.load(os.path.join(golden_dir, "crop_regions.npz"))
+    frame = np.random.default_rng(int(g["frame_seed"])).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    for corners, region, ext, s in zip(g["corners"], g["regions"], g["extents"], g["crop_sums"]):
+        c = [tuple(int(v) for v in corners[0]), tuple(int(v) for v in corners[1])]
+        assert img.determine_chimney_extents(c) == tuple(int(v) for v in ext)
+        got = img.generate_crop_region(c)
+        assert [tuple(p) for p in got] == [tuple(int(v) for v in p) for p in region]
+        assert int(img.crop_frame(frame, got).astype(np.int64).sum()) == int(s)
+
+
+def test_extract_segment_images_golden(golden_dir):
+    from swiftwatcher_amd import image_filtering as img
+    g = np.load(os.path.join(golden_dir, "segment_crops.npz"))
+    frame = np.random.default_rng(int(g["frame_seed"])).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    cr = [tuple(int(v) for v in g["crop_region"][0]), tuple(int(v) for v in g["crop_region"][1])]
+    segs = [img.RegionProps(1, tuple(int(v) for v in b), (0.0, 0.0), 1) for b in g["bboxes"]]
+    ims = img.extract_segment_images(segs, frame, (24, 24), cr)
+    for im, shp, s, fp, lp in zip(ims, g["shapes"], g["sums"], g["first_px"], g["last_px"]):
+        assert im.shape == tuple(shp) and int(im.astype(np.int64).sum()) == int(s)
+        np.testing.assert_array_equal(im[0, 0], fp)
+        np.testing.assert_array_equal(im[-1, -1], lp)
+
+
+def test_framequeue_bookkeeping():
+    from swiftwatcher_amd.data_structures import FrameQueue, Frame
+    q = FrameQueue(queue_size=5)
+    assert q.maxlen == 5 and q.is_empty()
+    frames = [np.full((8, 8, 3), i, np.uint8) for i in range(5)]
+    q.push_list_of_frames(frames, [0, 1, 2, -1, -1], ["a", "b", "c", "00:00:00.000", "00:00:00.000"])
+    assert q.frames_read == 5 and q[0].null and not q[4].null      # newest (left) = last pushed
+    assert [f.frame_number for f in q] == [-1, -1, 2, 1, 0]
+    q.preprocess_queue([(2, 1), (6, 5)], None)
+    assert q[0].processed_frames["crop"].shape == (4, 4, 3)
+    assert list(q[0].processed_frames.keys()) == ["crop", "grayscale"]
+    first = q.pop_frame()
+    assert first.frame_number == 0 and q.frames_processed == 1
+    q.pop_frame(); q.pop_frame()
+    assert q.frames_processed == 3
+    q.pop_frame(); q.pop_frame()
+    assert q.frames_processed == 3 and q.is_empty()               # null frames are not counted
+    assert Frame().null

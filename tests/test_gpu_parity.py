@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path (through the C ABI, swiftwatcher_amd/_lib.py) against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and -- at full
+benchmark size -- through size-independent properties.  Integer/byte/index results must be
+bit-exact; float64 RPCA factors within 1e-5 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL_AE = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from swiftwatcher_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import reference_path
+    return reference_path
+
+
+def _segs(res, i):
+    return [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"]),
+             int(s["sum_r"]), int(s["sum_c"])) for s in res["segs"][i, :res["nseg"][i]]]
+
+
+def _orc_segs(seglist):
+    return [(s["label"],) + s["bbox"] + (s["area"], s["sum_r"], s["sum_c"]) for s in seglist]
+
+
+# ------------------------------------------------------------------ stage level
+def test_bgr2gray(ctx, orc):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(3, 37, 61, 3), dtype=np.uint8)
+    for mode in (0, 1):
+        got = ctx.bgr2gray(img, mode)
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], orc.bgr2gray(img[i], mode))
+
+
+def test_rpca_epilogue(ctx, orc):
+    rng = np.random.default_rng(2)
+    E = rng.normal(0, 80, size=5000)
+    E[:8] = [0.0, -0.0, -0.999999, -1.0, -255.0, -255.5, -300.0, 12.0]
+    np.testing.assert_array_equal(ctx.rpca_epilogue(E), orc.rpca_epilogue(E))
+
+
+@pytest.mark.parametrize("shape", [(12, 13), (64, 96), (107, 214), (33, 65)])
+@pytest.mark.parametrize("fma", [False, True])
+def test_bilateral(ctx, orc, shape, fma):
+    rng = np.random.default_rng(3)
+    sparse = (rng.random((3,) + shape) < 0.15) * rng.integers(1, 256, size=(3,) + shape)
+    dense = rng.integers(0, 256, size=(1,) + shape)
+    imgs = np.concatenate([sparse, dense]).astype(np.uint8)
+    got = ctx.bilateral_u8(imgs, 7, 15.0, 1.0, fma)
+    for i in range(imgs.shape[0]):
+        np.testing.assert_array_equal(got[i], orc.bilateral_u8(imgs[i], 7, 15.0, 1.0, fma))
+    # other diameters through the generic kernel
+    got5 = ctx.bilateral_u8(imgs[0], 5, 20.0, 2.0, fma)
+    np.testing.assert_array_equal(got5, orc.bilateral_u8(imgs[0], 5, 20.0, 2.0, fma))
+
+
+def test_thresh(ctx, orc):
+    src = np.arange(256, dtype=np.uint8).repeat(3)
+    np.testing.assert_array_equal(ctx.thresh_tozero_u8(src, 15), orc.thresh_tozero_u8(src, 15))
+    np.testing.assert_array_equal(ctx.thresh_tozero_u8(src, 200), orc.thresh_tozero_u8(src, 200))
+
+
+def test_grey_opening_golden_and_random(ctx, orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "grey_opening.npz"))
+    for i in range(int(g["count"])):
+        np.testing.assert_array_equal(ctx.grey_open3x3_u8(g["in%d" % i]), g["out%d" % i])
+    rng = np.random.default_rng(4)
+    for shape in [(212, 424), (31, 33), (32, 64), (33, 65), (2, 2)]:
+        im = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        np.testing.assert_array_equal(ctx.grey_open3x3_u8(im), orc.grey_open_u8(im))
+
+
+@pytest.mark.parametrize("conn,order", [(8, 1), (8, 0), (4, 0), (4, 1)])
+def test_ccl(ctx, orc, conn, order):
+    rng = np.random.default_rng(5)
+    cases = [((31, 45), 0.45), ((64, 64), 0.6), ((5, 9), 0.5), ((212, 424), 0.08), ((107, 213), 0.3),
+             ((16, 16), 0.0), ((16, 16), 1.0), ((1, 40), 0.5), ((40, 1), 0.5)]
+    for shape, dens in cases:
+        im = ((rng.random(shape) < dens) * rng.integers(1, 256, size=shape)).astype(np.uint8)
+        n, lab = ctx.ccl_u8(im, conn, order)
+        nref, ref = orc.ccl_u8(im, conn, order)
+        assert n == nref
+        np.testing.assert_array_equal(lab, ref)
+    # spiral / comb shapes stress long union chains
+    comb = np.zeros((64, 128), np.uint8)
+    comb[::2, :] = 9
+    comb[:, 0] = 9
+    n, lab = ctx.ccl_u8(comb, conn, order)
+    nref, ref = orc.ccl_u8(comb, conn, order)
+    assert n == nref == 1
+    np.testing.assert_array_equal(lab, ref)
+
+
+def test_ccl_batch_more_than_255_components(ctx, orc):
+    rng = np.random.default_rng(6)
+    ims = ((rng.random((4, 80, 120)) < 0.2) * 200).astype(np.uint8)
+    nc, lab = ctx.ccl_u8(ims, 8, 1)
+    for i in range(4):
+        nref, ref = orc.ccl_u8(ims[i], 8, 1)
+        assert nc[i] == nref and nref > 255
+        np.testing.assert_array_equal(lab[i], ref)
+
+
+def test_regionprops_golden_and_wrap(ctx, orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "regionprops.npz"))
+    for i in range(int(g["count"])):
+        segs, n = ctx.regionprops_u8(g["lab%d" % i])
+        assert n == len(g["labels%d" % i])
+        assert [int(s["label"]) for s in segs] == list(g["labels%d" % i])
+        assert [(int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"])) for s in segs] == [tuple(b) for b in g["bbox%d" % i]]
+        cen = np.array([(int(s["sum_r"]) / int(s["area"]), int(s["sum_c"]) / int(s["area"])) for s in segs])
+        np.testing.assert_array_equal(cen, g["centroid%d" % i])
+    rng = np.random.default_rng(7)
+    lab = rng.integers(0, 256, size=(3, 90, 130)).astype(np.uint8)
+    segs, nseg = ctx.regionprops_u8(lab)
+    for i in range(3):
+        exp = orc.regionprops_u8(lab[i])
+        assert nseg[i] == len(exp) == 255
+        got = [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"]), int(s["sum_r"]), int(s["sum_c"]))
+               for s in segs[i, :nseg[i]]]
+        assert got == _orc_segs(exp)
+
+
+# ------------------------------------------------------------------ IALM
+# ialm_40x48x64 has only 1920 pixels for 64 frames: cond(M)^2 ~ 1e8 enters the Gram-matrix route
+# (and LAPACK's own answers differ by 5e-8 between numpy builds on it), so it gets a looser bound.
+@pytest.mark.parametrize("name,atol", [("ialm_128x160x7", ATOL_AE), ("ialm_64x96x21", ATOL_AE),
+                                       ("ialm_64x96x64", ATOL_AE), ("ialm_107x214x21", ATOL_AE),
+                                       ("ialm_40x48x64", 1e-4)])
+def test_ialm_golden(ctx, orc, golden_dir, name, atol):
+    """HIP IALM against fixtures produced by the reference's own function."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    frames = g["frames"]
+    n, H, W = frames.shape
+    A, E, iters = ctx.ialm(frames.reshape(n, H * W))
+    assert iters == int(g["iters"])
+    rows = g["rows"]
+    np.testing.assert_allclose(A[rows], g["A_rows"], atol=atol, rtol=0)
+    np.testing.assert_allclose(E[rows], g["E_rows"], atol=atol, rtol=0)
+    np.testing.assert_allclose(A.sum(axis=0), g["A_colsum"], rtol=1e-8)
+    np.testing.assert_array_equal(ctx.rpca_epilogue(E).T.reshape(n, H, W), g["sparse"])
+
+
+def test_ialm_vs_oracle_and_null_frames(ctx, orc):
+    from swiftwatcher_amd import synthetic
+    roi = synthetic.roi_window(11, 21, 64, 96, birds=4, bird_len=(8, 14), bird_wid=(3, 6), null_frames=4)
+    gray = np.stack([orc.bgr2gray(f) for f in roi])
+    X = gray.reshape(21, -1)
+    A, E, it = ctx.ialm(X)
+    A0, E0, it0 = orc.ialm_defined(X.T, return_iters=True)
+    assert it == it0
+    np.testing.assert_allclose(A, A0, atol=ATOL_AE, rtol=0)
+    np.testing.assert_allclose(E, E0, atol=ATOL_AE, rtol=0)
+    assert not A[:, :4].any() and not E[:, :4].any()
+    # all-zero window: defined as zeros, zero iterations
+    A, E, it = ctx.ialm(np.zeros((5, 300), np.uint8))
+    assert it == 0 and not A.any() and not E.any()
+
+
+# ------------------------------------------------------------------ whole window
+@pytest.mark.parametrize("n,Hc,Wc,birds", [(21, 107, 214, 6), (7, 128, 160, 3), (64, 48, 80, 3)])
+def test_window_all_stages(ctx, orc, n, Hc, Wc, birds):
+    from swiftwatcher_amd import synthetic
+    roi = synthetic.roi_window(100 + n, n, Hc, Wc, birds=birds, bird_len=(10, 15), bird_wid=(4, 7))
+    res = ctx.batch_run(roi, 1, n, want_A=True, want_E=True)
+    ref = orc.window(roi)
+    for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+        np.testing.assert_array_equal(res[key], ref[key], err_msg=key)
+    assert int(res["nseg"].sum()) > 0
+    for i in range(n):
+        assert _segs(res, i) == _orc_segs(ref["segments"][i])
+
+
+def test_batch_of_windows_with_crop_from_full_frames(ctx, orc):
+    """Several windows per call, ROI cropped on the device side of the boundary from whole frames,
+    different content per window (so per-window iteration counts may differ)."""
+    from swiftwatcher_amd import synthetic
+    crop_region = [(40, 30), (40 + 120, 30 + 60)]
+    nwin, n = 3, 21
+    frames = np.concatenate([synthetic.full_frames(200 + w, n, crop_region, frame_hw=(128, 200), birds=2 + w,
+                                                   bird_len=(8, 12), bird_wid=(3, 5)) for w in range(nwin)])
+    res = ctx.batch_run(frames, nwin, n, crop=(40, 30, 120, 60))
+    for w in range(nwin):
+        roi = frames[w * n:(w + 1) * n, 30:90, 40:160]
+        ref = orc.window(np.ascontiguousarray(roi))
+        sl = slice(w * n, (w + 1) * n)
+        for key in ("gray", "rpca", "opened", "labels"):
+            np.testing.assert_array_equal(res[key][sl], ref[key], err_msg="%s window %d" % (key, w))
+        for i in range(n):
+            assert _segs(res, w * n + i) == _orc_segs(ref["segments"][i])
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 size (424x212 ROI, 64-frame window): properties that need no oracle run.
+    A + E must reproduce X to the IALM tolerance, the sparse image equals clip(-E), labels are
+    consistent with the opened image, region areas sum to the foreground count."""
+    from swiftwatcher_amd import synthetic
+    roi = synthetic.roi_window(5, 64, 212, 424, birds=12)
+    res = ctx.batch_run(roi, 1, 64, want_A=True, want_E=True)
+    X = res["gray"].reshape(64, -1).T.astype(np.float64)
+    A, E = res["A"][0], res["E"][0]
+    assert 5 <= res["iters"][0] < 100
+    assert np.linalg.norm(X - A - E) / np.linalg.norm(X) < 1e-3
+    S = np.clip(-E, 0, 255).astype(np.uint8).T.reshape(64, 212, 424)
+    np.testing.assert_array_equal(S, res["rpca"])
+    assert np.array_equal(res["labels"] != 0, res["opened"] != 0)
+    for i in range(64):
+        seg = res["segs"][i, :res["nseg"][i]]
+        assert int(seg["area"].sum()) == int((res["opened"][i] != 0).sum())
+        assert list(seg["label"]) == sorted(seg["label"])
+    assert res["nseg"].max() >= 6
+
+
+# ------------------------------------------------------------------ drop-in surface
+def test_framequeue_drop_in(orc):
+    from swiftwatcher_amd import synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    crop_region = [(40, 30), (40 + 120, 30 + 60)]
+    n = 21
+    frames = synthetic.full_frames(9, n, crop_region, frame_hw=(128, 200), birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+    q = FrameQueue()
+    assert q.maxlen == 21
+    # the reader hands frames oldest first; the queue keeps the newest at index 0
+    order = list(range(n - 1, -1, -1))
+    q.push_list_of_frames([frames[i] for i in order], list(range(n)), ["t%d" % i for i in range(n)])
+    q.preprocess_queue(crop_region, (300, 150))
+    q.segment_queue((24, 24), crop_region)
+    roi = np.ascontiguousarray(frames[:, 30:90, 40:160])
+    ref = orc.window(roi)
+    keys = ["crop", "grayscale", "RPCA", "bilateral", "thresh_15", "opened", "cc_labeling"]
+    for pos in range(n):
+        f = q[pos]
+        assert list(f.processed_frames.keys()) == keys
+        np.testing.assert_array_equal(f.processed_frames["cc_labeling"], ref["labels"][pos])
+        np.testing.assert_array_equal(f.processed_frames["RPCA"], ref["rpca"][pos])
+        assert [s.label for s in f.segments] == [s["label"] for s in ref["segments"][pos]]
+        for s, r in zip(f.segments, ref["segments"][pos]):
+            assert s.bbox == r["bbox"] and s.centroid == r["centroid"]
+            box = orc.segment_crop_box(r["bbox"], (24, 24), crop_region)
+            np.testing.assert_array_equal(s.segment_image, f.frame[box[0]:box[2], box[1]:box[3]])
+            assert s.status is None and s.segment_history == []
+    popped = q.pop_frame()
+    assert popped.frame_number == 0 and q.frames_processed == 1

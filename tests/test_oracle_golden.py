@@ -54,7 +54,7 @@ def test_regionprops(golden_dir):
         np.testing.assert_array_equal(np.array([s["centroid"] for s in got]), g["centroid%d" % i])
 
 
-IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_107x214x21"]
+IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64", "ialm_107x214x21"]
 
 
 @pytest.mark.parametrize("name", IALM_CASES)
