@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the segment hot path (BASELINE.json configs[1]):
+
+    synthetic 1080p ROI stream (424x212 crop of a 340-px chimney), frame-batch = 64
+    (FrameQueue(queue_size=64)), image_filtering HIP kernels, one MI355X per rank.
+
+A "step" is one swk_batch_run over `--windows` independent 64-frame RPCA windows whose BGR ROI
+frames are already resident in HBM; products (u8 label planes, per-frame segment records,
+iteration counts) stay in HBM.  value = ROI frames/s over all ranks.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_STEADY = 33              # per element per iteration: X u8 + A,Y f64 read, A,Y f64 written
+BYTES_FIRST = 17               # first iteration: previous state is implicit (no A/Y read)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--windows", type=int, default=32, help="64-frame windows per step per GPU")
+    ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
+    ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
+    ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=1, help="windows in the CPU baseline sample")
+    ap.add_argument("--host-input", action="store_true", help="also time a step fed from host memory (PCIe inclusive)")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, Hc, Wc, nwin, seed=424242):
+    """The CPU oracle (numpy + C restatement of the reference path) on a bounded sample of the same
+    workload.  kind = "port": the reference's own cv2 stages cannot run anywhere in this image."""
+    import numpy as np
+    from swiftwatcher_amd import synthetic
+    from oracle import reference_path as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rois = [synthetic.roi_window(seed + w, n, Hc, Wc) for w in range(nwin)]
+    t0 = time.perf_counter()
+    nseg = 0
+    for roi in rois:
+        res = orc.window(roi)
+        nseg += sum(len(s) for s in res["segments"])
+    dt = time.perf_counter() - t0
+    return dict(value=round(nwin * n / dt, 3), unit="frames/s", cores=int(threads), kind="port",
+                sample="%d window(s) of %d frames at %dx%d ROI: numpy/LAPACK SVD IALM (BLAS threads=%d) + "
+                       "single-threaded C for the byte stages, %.1f s" % (nwin, n, Wc, Hc, threads, dt))
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from swiftwatcher_amd import _lib, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    geo = getattr(synthetic, args.size)
+    Hc, Wc, n, nwin = geo["Hc"], geo["Wc"], args.n, args.windows
+    F, P = nwin * n, Hc * Wc
+
+    # ---- synthetic stream, resident in HBM (each rank its own "videos": weak scaling) ----
+    frames = synthetic.roi_stream_torch(dev, F, Hc, Wc, seed=20190816 + 1000 * rank,
+                                        bird_len=geo["bird_len"], bird_wid=geo["bird_wid"])
+    labels = torch.empty((F, Hc, Wc), dtype=torch.uint8, device=dev)
+    seg_cap = 64
+    segs = torch.empty((F, seg_cap, 48), dtype=torch.uint8, device=dev)
+    nseg = torch.empty((F,), dtype=torch.int32, device=dev)
+    iters = torch.empty((nwin,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = _lib.Context(local, nwin, n, Hc, Wc)
+    ctx.set_ialm_variant(args.variant)
+    params = _lib.default_params()
+    inp = _lib.Input(frames=frames.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
+                     x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)
+    out = _lib.Output(mem=_lib.MEM_DEVICE, seg_cap=seg_cap)
+    out.labels = labels.data_ptr()
+    out.segs = segs.data_ptr()
+    out.nseg = nseg.data_ptr()
+    out.iters = iters.data_ptr()
+
+    def step():
+        ctx.batch_run_raw(inp, params, out)      # synchronous on the library's own stream
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+
+    # ---- per-rank counts gathered over RCCL (the only collective of the path) ----
+    it_host = iters.cpu().numpy()
+    nseg_host = nseg.cpu().numpy()
+    counts = torch.tensor([F * args.steps, int(nseg_host.sum()), int(it_host.sum())], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        gathered = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(gathered, counts)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_frames = int(sum(int(g[0]) for g in gathered))
+    else:
+        total_frames = int(counts[0])
+    dt_max = float(tmax[0])
+
+    if rank == 0:
+        pass_ms, pass_launches = prof["ialm_pass"]
+        # exact algorithmic bytes streamed by the full passes of ONE step (same every step: same data)
+        elems = n * P
+        step_bytes = int(sum(BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems
+        total_bytes = step_bytes * args.steps
+        achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_ialm_pass.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "frames/sec (segment) on 1080p ROI batches",
+            "value": round(total_frames / dt_max, 2),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 1080p ROI stream %dx%d, frame-batch=%d, %d windows/step/GPU, "
+                                   "image_filtering HIP kernels (gray, RPCA/IALM, bilateral, threshold, opening, CCL, "
+                                   "region props)" % (Wc, Hc, n, nwin),
+                       "roi": [Wc, Hc], "frame_batch": n, "windows_per_step": nwin,
+                       "ialm_iters_mean": round(float(it_host.mean()), 2),
+                       "segments_per_frame": round(float(nseg_host.mean()), 2),
+                       "parallelism": "windows sharded per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
+                         "bytes_per_launch": int(total_bytes / max(pass_launches, 1))},
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if isinstance(v, tuple)},
+        }
+        if args.host_input:
+            host = frames.cpu().numpy()
+            hin = _lib.Input(frames=host.ctypes.data, mem=_lib.MEM_HOST, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
+                             x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)
+            ctx.batch_run_raw(hin, params, out)
+            t1 = time.perf_counter()
+            ctx.batch_run_raw(hin, params, out)
+            res["pcie_inclusive_frames_per_s"] = round(F / (time.perf_counter() - t1), 2)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
