@@ -103,11 +103,11 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
     const double dual = st.dual_norm;
-    const int64_t wbase = (int64_t)w * n * P;
+    const int64_t wbase = (int64_t)w * n * P, ps = b.pstride;
     const uint8_t *X = b.X + wbase;
-    double *A = b.A + wbase, *Y = b.Y + wbase;
+    double *A = b.A + (int64_t)w * b.fpad * ps, *Y = b.Y + (int64_t)w * b.fpad * ps;
     uint8_t *S = b.S + wbase;
-    double *Eo = WRITE_E ? b.E + wbase : nullptr;
+    double *Eo = WRITE_E ? b.E + (int64_t)w * b.fpad * ps : nullptr;
     const double *Bm = b.Bm + (int64_t)w * n * n;
 
     for (int j = n; j < n8; ++j) { sm[j * kLdsRow + t] = 0.0; se[j * kLdsRow + t] = 0.0; }
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
         const int pc = valid ? p : P - 1;
         if (MODE != 0) {
             for (int j = 0; j < n; ++j) {
-                const int64_t idx = (int64_t)j * P + pc;
-                const double x = (double)X[idx];
+                const int64_t idx = (int64_t)j * ps + pc;
+                const double x = (double)X[(int64_t)j * P + pc];
                 double a, y;
                 if (MODE == 1) { a = 0.0; y = x / dual; }                 // :272-273
                 else { a = A[idx]; y = Y[idx]; }
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
             }
         }
         for (int i = 0; i < n; ++i) {
-            const int64_t idx = (int64_t)i * P + pc;
-            const double x = (double)X[idx];
+            const int64_t idx = (int64_t)i * ps + pc;
+            const double x = (double)X[(int64_t)i * P + pc];
             double a_new, y;
             if (MODE == 0) {
                 a_new = 0.0;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
                     zz += z * z;
                     A[idx] = a_new;
                     Y[idx] = y;
-                    S[idx] = sparse_u8(e);
+                    S[(int64_t)i * P + pc] = sparse_u8(e);
                     if (WRITE_E) Eo[idx] = e;
                 }
             }
@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
     const double *gp = b.gpart + (int64_t)w * nblk * n * n;
     for (int idx = tid; idx < n * n; idx += 256) {
         double acc = 0.0;
-        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + idx];
         const int i = idx / n, j = idx % n;
+        // the MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): mirror the rest
+        const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
+        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + src];
         G[i * kJac + j] = acc;
         V[i * kJac + j] = i == j ? 1.0 : 0.0;
     }
@@ -331,14 +333,14 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
 }
 
 // planes [nwin][n][P] -> reference layout [nwin][P][n]
-__global__ void k_planes_to_pn(const double *__restrict__ planes, double *__restrict__ out, int n, int P)
+__global__ void k_planes_to_pn(const double *__restrict__ planes, double *__restrict__ out, int n, int P, int64_t ps, int fpad)
 {
     const int w = blockIdx.y;
     const int64_t total = (int64_t)n * P;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int p = (int)(i / n), j = (int)(i % n);
-    out[(int64_t)w * total + i] = planes[(int64_t)w * total + (int64_t)j * P + p];
+    out[(int64_t)w * total + i] = planes[(int64_t)w * fpad * ps + (int64_t)j * ps + p];
 }
 
 __global__ void k_rpca_epilogue(const double *__restrict__ E, int64_t count, uint8_t *__restrict__ S)
@@ -352,7 +354,17 @@ __global__ void k_rpca_epilogue(const double *__restrict__ E, int64_t count, uin
 // ---------------------------------------------------------------------------------
 int ialm_pass_nblk(int variant, int n, int P, int nwin)
 {
-    (void)variant; (void)n;
+    (void)n;
+    if (variant == 2) {
+        // 256-thread blocks, 2 per CU resident (LDS), 16-pixel tiles per wave: about 512 blocks in all
+        const int ntiles = (P + 15) / 16;
+        int per_win = (512 + nwin - 1) / nwin;
+        const int cap = (ntiles + 7) / 8;          // at least two tiles per wave
+        if (per_win > cap) per_win = cap;
+        if (per_win > 64) per_win = 64;
+        if (per_win < 1) per_win = 1;
+        return per_win;
+    }
     const int ntiles = (P + 63) / 64;
     // enough blocks to fill 256 CUs a few times over, few enough that the Gram partial
     // slabs stay small next to the 34 B/element stream
@@ -407,10 +419,10 @@ void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda,
     hipLaunchKernelGGL(k_ialm_small, dim3(b.nwin), dim3(256), 0, s, b, k, lmbda, tol, maxiter);
 }
 
-void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P)
+void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad)
 {
     const int64_t total = (int64_t)n * P;
-    hipLaunchKernelGGL(k_planes_to_pn, dim3((unsigned)((total + 255) / 256), nwin), dim3(256), 0, s, planes, out, n, P);
+    hipLaunchKernelGGL(k_planes_to_pn, dim3((unsigned)((total + 255) / 256), nwin), dim3(256), 0, s, planes, out, n, P, pstride, fpad);
 }
 
 void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S)

@@ -43,6 +43,8 @@ struct swk_ctx {
     int64_t prof_n[SWK_K_COUNT] = {0};
     int64_t window_iters = 0;
     int ialm_variant = 0;
+    int64_t pstride = 0;                 // plane pitch of the A/Y/E workspaces of the last IALM run
+    int fpad = 0;                        // planes per window in them
 };
 
 namespace {
@@ -184,12 +186,18 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     int variant = ctx->ialm_variant;
-    if (variant == 0) variant = 1;
+    if (variant == 0) variant = 2;
     b.nblk = ialm_pass_nblk(variant, n, P, nwin);
+    b.pstride = ((int64_t)P + 15) & ~(int64_t)15;
+    b.fpad = (n + 15) & ~15;
+    ctx->pstride = b.pstride;
+    ctx->fpad = b.fpad;
+    if ((int64_t)b.fpad * b.pstride >= (1ll << 28)) return fail(ctx, SWK_ERR_ARG, "window too large: frames x ROI pixels must stay below 2^28");
     const size_t elems = (size_t)nwin * n * P;
-    NEED(ctx, SL_A, elems * 8, b.A);
-    NEED(ctx, SL_Y, elems * 8, b.Y);
-    if (want_E) NEED(ctx, SL_E, elems * 8, b.E);
+    const size_t felems = (size_t)nwin * b.fpad * b.pstride;
+    NEED(ctx, SL_A, felems * 8, b.A);
+    NEED(ctx, SL_Y, felems * 8, b.Y);
+    if (want_E) NEED(ctx, SL_E, felems * 8, b.E);
     NEED(ctx, SL_BM, (size_t)nwin * n * n * 8, b.Bm);
     NEED(ctx, SL_VPREV, (size_t)nwin * n * n * 8, b.Vprev);
     NEED(ctx, SL_GPART, (size_t)nwin * b.nblk * n * n * 8, b.gpart);
@@ -201,8 +209,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16, s));
     HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
     // a window that stops before writing A (all-zero input) must still read back zeros
-    HIPCHK(ctx, hipMemsetAsync(b.A, 0, elems * 8, s));
-    if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, elems * 8, s));
+    HIPCHK(ctx, hipMemsetAsync(b.A, 0, felems * 8, s));
+    if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, felems * 8, s));
     { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, b); launch_ialm_init(s, b, lmbda); }
     // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
     // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
@@ -297,8 +305,9 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
         rc = rc ? rc : need(ctx, SL_S, elems, &p);
         rc = rc ? rc : need(ctx, SL_OPEN, elems, &p);
         rc = rc ? rc : need(ctx, SL_LAB8, elems, &p);
-        rc = rc ? rc : need(ctx, SL_A, elems * 8, &p);
-        rc = rc ? rc : need(ctx, SL_Y, elems * 8, &p);
+        const size_t felems = (size_t)max_windows * ((max_n + 15) & ~15) * (((size_t)max_Hc * max_Wc + 15) & ~(size_t)15);
+        rc = rc ? rc : need(ctx, SL_A, felems * 8, &p);
+        rc = rc ? rc : need(ctx, SL_Y, felems * 8, &p);
         if (rc) { g_create_error = ctx->err; swk_ctx_destroy(ctx); return rc; }
     }
     *out = ctx;
@@ -435,7 +444,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
             const double *planes = (const double *)ctx->slot[which == 0 ? SL_A : SL_E];
             double *pn;
             if (dev_out) pn = dst; else NEED(ctx, SL_PN, elems * 8, pn);
-            { Timed t(ctx, SWK_K_COPY); launch_planes_to_pn(s, planes, pn, in->nwin, in->n, P); }
+            { Timed t(ctx, SWK_K_COPY); launch_planes_to_pn(s, planes, pn, in->nwin, in->n, P, ctx->pstride, ctx->fpad); }
             if (!dev_out) { rc = copy_out(ctx, dst, pn, elems * 8, out->mem); if (rc) return rc; HIPCHK(ctx, hipStreamSynchronize(s)); }
         }
     }
@@ -483,7 +492,7 @@ int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P, doub
         if (!dst) continue;
         double *pn;
         NEED(ctx, SL_PN, elems * 8, pn);
-        launch_planes_to_pn(ctx->stream, (const double *)ctx->slot[which == 0 ? SL_A : SL_E], pn, 1, n, P);
+        launch_planes_to_pn(ctx->stream, (const double *)ctx->slot[which == 0 ? SL_A : SL_E], pn, 1, n, P, ctx->pstride, ctx->fpad);
         HIPCHK(ctx, hipMemcpyAsync(dst, pn, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }

@@ -34,6 +34,8 @@ struct IalmBuffers {
     IalmWin *win;                  // [nwin]
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;
+    int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
+    int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows
 };
 
 // ialm.hip
@@ -41,7 +43,7 @@ void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant);
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter);
-void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P);
+void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad);
 void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S);
 int  ialm_pass_nblk(int variant, int n, int P, int nwin);
 

@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 ATOL_AE = 1e-5
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[2, 1], ids=["ialm_mfma", "ialm_lds"])
+def ctx(request):
+    """Every test runs against both IALM pass kernels: 2 = MFMA f64 (the default), 1 = LDS/VALU."""
     from swiftwatcher_amd import _lib
     c = _lib.Context(0)
+    c.set_ialm_variant(request.param)
     yield c
     c.close()
 
