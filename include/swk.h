@@ -185,6 +185,9 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
 /* Select the IALM pass kernel: 0 = auto, 1 = LDS/VALU kernel (any n <= 64),
  * 2 = MFMA f64 kernel.  For A/B measurements only. */
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
+/* Window groups whose eigen-solves overlap the other groups' streaming passes:
+ * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */
+int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);
 
 #ifdef __cplusplus
 }

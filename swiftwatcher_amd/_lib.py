@@ -84,6 +84,7 @@ _SIGS = {
     "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -175,6 +176,9 @@ class Context:
 
     def set_ialm_variant(self, variant):
         self._check(self._lib.swk_set_ialm_variant(self._h, int(variant)))
+
+    def set_ialm_groups(self, groups):
+        self._check(self._lib.swk_set_ialm_groups(self._h, int(groups)))
 
     # ---- hot path ----
     def batch_run_raw(self, inp, params, out):

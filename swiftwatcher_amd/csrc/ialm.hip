@@ -199,10 +199,16 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
 }
 
 // ---------------------------------------------------------------------------------
-// One workgroup per window: convergence test, mu update, Gram reduction, Jacobi
-// eigen-solve of G (n x n, f64, in LDS), B = I - G^(-1/2)/mu.
+// One workgroup (1024 threads) per window: convergence test, mu update, Gram reduction,
+// cyclic Jacobi eigen-solve of G (n x n, f64, in LDS), B = I - G^(-1/2)/mu.
+//
+// Jacobi with round-robin ordering: every round applies m/2 disjoint rotations.  A round is two
+// phases: (a) 32 lanes compute (c, s) of their pair; (b) G <- J^T G J is applied per 2x2 block
+// (rows of pair a, columns of pair b): each block only needs its own four entries and the two
+// rotations, so all (m/2)^2 blocks update in place, concurrently; V <- V J alongside.
 // ---------------------------------------------------------------------------------
 constexpr int kJac = 65;    // LDS row pitch of the n x n matrices
+constexpr int kSmallThreads = 1024;
 
 __device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, int &q)
 {
@@ -211,11 +217,11 @@ __device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, in
     if (p > q) { int tmp = p; p = q; q = tmp; }
 }
 
-__global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter)
+__global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter)
 {
     __shared__ double G[kMaxN * kJac];
     __shared__ double V[kMaxN * kJac];
-    __shared__ double red[256];
+    __shared__ double red[kSmallThreads];
     __shared__ double cs_c[kMaxN / 2], cs_s[kMaxN / 2];
     __shared__ int pq_p[kMaxN / 2], pq_q[kMaxN / 2];
     __shared__ double wgt[kMaxN];
@@ -226,10 +232,10 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
 
     if (k >= 1) {
         double acc = 0.0;
-        for (int i = tid; i < nblk; i += 256) acc += b.zzpart[(int64_t)w * nblk + i];
+        for (int i = tid; i < nblk; i += kSmallThreads) acc += b.zzpart[(int64_t)w * nblk + i];
         red[tid] = acc;
         __syncthreads();
-        for (int s = 128; s; s >>= 1) {
+        for (int s = kSmallThreads / 2; s; s >>= 1) {
             if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
 
     // deterministic reduction of the per-block Gram partials
     const double *gp = b.gpart + (int64_t)w * nblk * n * n;
-    for (int idx = tid; idx < n * n; idx += 256) {
+    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
         double acc = 0.0;
         const int i = idx / n, j = idx % n;
         // the MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): mirror the rest
@@ -257,9 +263,12 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
         G[i * kJac + j] = acc;
         V[i * kJac + j] = i == j ? 1.0 : 0.0;
     }
+    if ((n & 1) && tid <= n) {                 // zero row/column at the dummy index of an odd n
+        G[n * kJac + tid] = 0.0;
+        G[tid * kJac + n] = 0.0;
+    }
     __syncthreads();
 
-    // cyclic Jacobi, round-robin ordering: m/2 disjoint rotations per round
     const int m = n + (n & 1), half = m / 2;
     int sweeps = 0;
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -273,8 +282,9 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
                 if (q < n) {
                     const double gpq = G[p * kJac + q], gpp = G[p * kJac + p], gqq = G[q * kJac + q];
                     if (gpq != 0.0 && fabs(gpq) > 1e-15 * sqrt(fabs(gpp * gqq))) {
-                        const double tau = (gqq - gpp) / (2.0 * gpq);
-                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (gqq - gpp) / (2 gpq), without forming tau
+                        const double d = gqq - gpp, b2 = 2.0 * gpq;
+                        const double tt = (d >= 0.0 ? b2 : -b2) / (fabs(d) + sqrt(d * d + b2 * b2));
                         c = 1.0 / sqrt(1.0 + tt * tt);
                         s = tt * c;
                         s_rot = 1;
@@ -283,29 +293,35 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
                 pq_p[tid] = p; pq_q[tid] = q; cs_c[tid] = c; cs_s[tid] = s;
             }
             __syncthreads();
-            for (int idx = tid; idx < n * half; idx += 256) {          // G <- G J, V <- V J
+            // G <- J^T G J, one 2x2 block (pair a rows, pair b columns) per item
+            for (int idx = tid; idx < half * half; idx += kSmallThreads) {
+                const int ka = idx / half, kb = idx % half;
+                const double sa = cs_s[ka], sb = cs_s[kb];
+                if (sa == 0.0 && sb == 0.0) continue;
+                const double ca = cs_c[ka], cb = cs_c[kb];
+                const int pa = pq_p[ka], qa = pq_q[ka], pb = pq_p[kb], qb = pq_q[kb];
+                // (for odd n the dummy index n is a zero row/column of G: rotating it is harmless)
+                const double g00 = G[pa * kJac + pb], g01 = G[pa * kJac + qb];
+                const double g10 = G[qa * kJac + pb], g11 = G[qa * kJac + qb];
+                // rows: (p, q) <- (c p - s q, s p + c q)
+                const double r00 = ca * g00 - sa * g10, r01 = ca * g01 - sa * g11;
+                const double r10 = sa * g00 + ca * g10, r11 = sa * g01 + ca * g11;
+                // columns likewise
+                G[pa * kJac + pb] = cb * r00 - sb * r01;
+                G[pa * kJac + qb] = sb * r00 + cb * r01;
+                G[qa * kJac + pb] = cb * r10 - sb * r11;
+                G[qa * kJac + qb] = sb * r10 + cb * r11;
+            }
+            // V <- V J
+            for (int idx = tid; idx < n * half; idx += kSmallThreads) {
                 const int i = idx / half, kk = idx % half;
                 const double s = cs_s[kk];
                 if (s == 0.0) continue;
                 const double c = cs_c[kk];
                 const int p = pq_p[kk], q = pq_q[kk];
-                const double gp_ = G[i * kJac + p], gq_ = G[i * kJac + q];
-                G[i * kJac + p] = c * gp_ - s * gq_;
-                G[i * kJac + q] = s * gp_ + c * gq_;
                 const double vp = V[i * kJac + p], vq = V[i * kJac + q];
                 V[i * kJac + p] = c * vp - s * vq;
                 V[i * kJac + q] = s * vp + c * vq;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < n * half; idx += 256) {          // G <- J^T G
-                const int j = idx % n, kk = idx / n;
-                const double s = cs_s[kk];
-                if (s == 0.0) continue;
-                const double c = cs_c[kk];
-                const int p = pq_p[kk], q = pq_q[kk];
-                const double gp_ = G[p * kJac + j], gq_ = G[q * kJac + j];
-                G[p * kJac + j] = c * gp_ - s * gq_;
-                G[q * kJac + j] = s * gp_ + c * gq_;
             }
             __syncthreads();
         }
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ialm_small(IalmBuffers b, int k, double
     }
     __syncthreads();
     double *Bm = b.Bm + (int64_t)w * n * n;
-    for (int idx = tid; idx < n * n; idx += 256) {
+    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
         const int i = idx / n, j = idx % n;
         double acc = 0.0;
         for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
@@ -356,12 +372,14 @@ int ialm_pass_nblk(int variant, int n, int P, int nwin)
 {
     (void)n;
     if (variant == 2) {
-        // 256-thread blocks, 2 per CU resident (LDS), 16-pixel tiles per wave: about 512 blocks in all
+        // 256-thread blocks, one resident per CU (the n = 64 kernel takes the whole register file).
+        // Several rounds of blocks per CU keep the tail short when a few CUs are busy with another
+        // group's eigen-solve; the cap bounds the Gram partial slabs (nblk x n^2 doubles per window).
         const int ntiles = (P + 15) / 16;
-        int per_win = (512 + nwin - 1) / nwin;
+        int per_win = (256 * 4 + nwin - 1) / nwin;
         const int cap = (ntiles + 7) / 8;          // at least two tiles per wave
         if (per_win > cap) per_win = cap;
-        if (per_win > 64) per_win = 64;
+        if (per_win > 128) per_win = 128;
         if (per_win < 1) per_win = 1;
         return per_win;
     }
@@ -416,7 +434,7 @@ void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant
 
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter)
 {
-    hipLaunchKernelGGL(k_ialm_small, dim3(b.nwin), dim3(256), 0, s, b, k, lmbda, tol, maxiter);
+    hipLaunchKernelGGL(k_ialm_small, dim3(b.nwin), dim3(kSmallThreads), 0, s, b, k, lmbda, tol, maxiter);
 }
 
 void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad)

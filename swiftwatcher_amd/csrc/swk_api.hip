@@ -22,6 +22,7 @@ enum Slot {
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
+constexpr int kMaxGroups = 8;
 
 }  // namespace
 
@@ -43,6 +44,12 @@ struct swk_ctx {
     int64_t prof_n[SWK_K_COUNT] = {0};
     int64_t window_iters = 0;
     int ialm_variant = 0;
+    int ialm_groups = 0;                 // 0 = auto
+    hipStream_t gstream[8] = {nullptr};  // side streams of the IALM window groups
+    hipEvent_t ev_pass[8] = {nullptr}, ev_small[8] = {nullptr}, ev_poll[8][2] = {{nullptr}};
+    int ngroups_ready = 0;
+    IalmWin *last_win = nullptr;         // per-window IALM state of the last run
+    int last_nwin = 0;
     int64_t pstride = 0;                 // plane pitch of the A/Y/E workspaces of the last IALM run
     int fpad = 0;                        // planes per window in them
 };
@@ -99,16 +106,29 @@ hipEvent_t take_event(swk_ctx *ctx)
 }
 
 struct Timed {
-    swk_ctx *ctx; int fam; hipEvent_t a{}, b{};
-    Timed(swk_ctx *c, int f) : ctx(c), fam(f)
+    swk_ctx *ctx; int fam; hipStream_t st; hipEvent_t a{}, b{};
+    Timed(swk_ctx *c, int f, hipStream_t stream = nullptr) : ctx(c), fam(f), st(stream ? stream : c->stream)
     {
-        if (ctx->prof_on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, ctx->stream); }
+        if (ctx->prof_on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, st); }
     }
     ~Timed()
     {
-        if (ctx->prof_on) { (void)hipEventRecord(b, ctx->stream); ctx->pending.push_back({a, b, fam}); }
+        if (ctx->prof_on) { (void)hipEventRecord(b, st); ctx->pending.push_back({a, b, fam}); }
     }
 };
+
+int ensure_groups(swk_ctx *ctx, int ngroups)
+{
+    for (int g = ctx->ngroups_ready; g < ngroups; ++g) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream[g], hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pass[g], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_small[g], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_poll[g][0], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_poll[g][1], hipEventDisableTiming));
+        ctx->ngroups_ready = g + 1;
+    }
+    return SWK_OK;
+}
 
 void drain_prof(swk_ctx *ctx)
 {
@@ -123,6 +143,7 @@ void drain_prof(swk_ctx *ctx)
 
 int sync(swk_ctx *ctx)
 {
+    for (int g = 0; g < ctx->ngroups_ready; ++g) HIPCHK(ctx, hipStreamSynchronize(ctx->gstream[g]));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     drain_prof(ctx);
@@ -187,7 +208,10 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     int variant = ctx->ialm_variant;
     if (variant == 0) variant = 2;
-    b.nblk = ialm_pass_nblk(variant, n, P, nwin);
+    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : (nwin >= 16 ? 4 : (nwin >= 4 ? 2 : 1));
+    if (ngroups > kMaxGroups) ngroups = kMaxGroups;
+    if (ngroups > nwin) ngroups = nwin;
+    b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
     b.pstride = ((int64_t)P + 15) & ~(int64_t)15;
     b.fpad = (n + 15) & ~15;
     ctx->pstride = b.pstride;
@@ -203,44 +227,99 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_GPART, (size_t)nwin * b.nblk * n * n * 8, b.gpart);
     NEED(ctx, SL_ZZPART, (size_t)nwin * b.nblk * 8, b.zzpart);
     NEED(ctx, SL_WIN, (size_t)nwin * sizeof(IalmWin), b.win);
-    NEED(ctx, SL_ACTIVE, 16, b.active);
+    NEED(ctx, SL_ACTIVE, 16 * sizeof(int), b.active);
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(b.win, 0, (size_t)nwin * sizeof(IalmWin), s));
-    HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16, s));
+    HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16 * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
     // a window that stops before writing A (all-zero input) must still read back zeros
     HIPCHK(ctx, hipMemsetAsync(b.A, 0, felems * 8, s));
     if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, felems * 8, s));
-    { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, b); launch_ialm_init(s, b, lmbda); }
-    // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
-    // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
-    { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, b, 0, variant); }
-    { Timed t(ctx, SWK_K_IALM_SMALL); launch_ialm_small(s, b, 0, lmbda, tol, maxiter); }
-    int active = nwin;
-    for (int k = 1; k <= maxiter; ++k) {
-        { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, b, k == 1 ? 1 : 2, variant); }
-        { Timed t(ctx, SWK_K_IALM_SMALL); launch_ialm_small(s, b, k, lmbda, tol, maxiter); }
-        ctx->window_iters += active;
-        if (k >= 6 || k == maxiter) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, b.active, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(ctx, hipStreamSynchronize(s));
-            active = *ctx->h_active;
-            if (active <= 0) break;
-        }
+
+    // Window groups.  The eigen-solve of a window runs on ONE compute unit for about a millisecond;
+    // a streaming pass over a group of windows takes about as long on the whole chip.  So the batch is
+    // cut into groups: all streaming passes go back to back on the main stream, each group's
+    // small-matrix kernel goes on the group's side stream, and events tie pass_g(k) -> small_g(k) ->
+    // pass_g(k+1).  While group g solves its eigenproblems the chip streams the other groups.
+    int rc = ensure_groups(ctx, ngroups);
+    if (rc) return rc;
+    struct Group { IalmBuffers b; int w0; bool finished; };
+    Group grp[kMaxGroups];
+    for (int g = 0; g < ngroups; ++g) {
+        const int w0 = (int)((int64_t)nwin * g / ngroups), w1 = (int)((int64_t)nwin * (g + 1) / ngroups);
+        Group &gr = grp[g];
+        gr.w0 = w0; gr.finished = false;
+        gr.b = b;
+        gr.b.nwin = w1 - w0;
+        gr.b.X = b.X + (size_t)w0 * n * P;
+        gr.b.S = b.S + (size_t)w0 * n * P;
+        gr.b.A = b.A + (size_t)w0 * b.fpad * b.pstride;
+        gr.b.Y = b.Y + (size_t)w0 * b.fpad * b.pstride;
+        gr.b.E = b.E ? b.E + (size_t)w0 * b.fpad * b.pstride : nullptr;
+        gr.b.Bm = b.Bm + (size_t)w0 * n * n;
+        gr.b.Vprev = b.Vprev + (size_t)w0 * n * n;
+        gr.b.gpart = b.gpart + (size_t)w0 * b.nblk * n * n;
+        gr.b.zzpart = b.zzpart + (size_t)w0 * b.nblk;
+        gr.b.win = b.win + w0;
+        gr.b.active = b.active + g;
     }
-    if (h_iters || d_iters) {
-        // iteration counts live in the per-window state structs; gather them
-        std::vector<IalmWin> hw(nwin);
-        HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        std::vector<int32_t> it(nwin);
-        for (int w = 0; w < nwin; ++w) it[w] = hw[w].iter;
-        if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
-        if (d_iters) {
-            HIPCHK(ctx, hipMemcpyAsync(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, s));
-            HIPCHK(ctx, hipStreamSynchronize(s));
-        }
+    const int check_from = 6;     // no window converges earlier (mu grows 1.5x per iteration)
+    for (int g = 0; g < ngroups; ++g) {
+        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, grp[g].b); launch_ialm_init(s, grp[g].b, lmbda); }
+        // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
+        // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
+        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant); }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
+        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]); launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter); }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], ctx->gstream[g]));
     }
+    for (int k = 1; k <= maxiter + 2; ++k) {
+        bool any = false;
+        for (int g = 0; g < ngroups; ++g) {
+            Group &gr = grp[g];
+            if (gr.finished) continue;
+            // convergence is polled two iterations late so the host never stalls the queues; the
+            // launches made meanwhile for an already finished group return at their first branch
+            const int kc = k - 2;
+            if (kc >= check_from) {
+                HIPCHK(ctx, hipEventSynchronize(ctx->ev_poll[g][kc & 1]));
+                if (ctx->h_active[g * 2 + (kc & 1)] <= 0) { gr.finished = true; continue; }
+            }
+            if (k > maxiter) { gr.finished = true; continue; }
+            any = true;
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
+            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant); }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
+            hipStream_t gs = ctx->gstream[g];
+            HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
+            { Timed t(ctx, SWK_K_IALM_SMALL, gs); launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter); }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
+            if (k >= check_from) {
+                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));
+                HIPCHK(ctx, hipEventRecord(ctx->ev_poll[g][k & 1], gs));
+            }
+        }
+        if (!any) break;
+    }
+    // everything after the IALM runs on the main stream: join the side streams
+    for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
+    ctx->last_win = b.win;
+    ctx->last_nwin = nwin;
+    (void)h_iters; (void)d_iters;
+    return SWK_OK;
+}
+
+// Iteration counts live in the per-window state structs.  Called once the stream has drained.
+int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
+{
+    const int nwin = ctx->last_nwin;
+    std::vector<IalmWin> hw(nwin);
+    HIPCHK(ctx, hipMemcpy(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost));
+    std::vector<int32_t> it(nwin);
+    for (int w = 0; w < nwin; ++w) { it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; }
+    if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
+    if (d_iters) HIPCHK(ctx, hipMemcpy(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice));
     return SWK_OK;
 }
 
@@ -291,7 +370,7 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
     swk_ctx *ctx = new swk_ctx();
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_active, 64, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_active, 256, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "stream / pinned memory creation failed";
         delete ctx;
         return SWK_ERR_HIP;
@@ -321,6 +400,12 @@ void swk_ctx_destroy(swk_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_prof(ctx);
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    for (int g = 0; g < ctx->ngroups_ready; ++g) {
+        (void)hipStreamSynchronize(ctx->gstream[g]);
+        (void)hipEventDestroy(ctx->ev_pass[g]); (void)hipEventDestroy(ctx->ev_small[g]);
+        (void)hipEventDestroy(ctx->ev_poll[g][0]); (void)hipEventDestroy(ctx->ev_poll[g][1]);
+        (void)hipStreamDestroy(ctx->gstream[g]);
+    }
     for (int i = 0; i < SL_COUNT; ++i)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
@@ -361,6 +446,13 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
     if (!ctx || variant < 0 || variant > 2) return SWK_ERR_ARG;
     ctx->ialm_variant = variant;
+    return SWK_OK;
+}
+
+int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups)
+{
+    if (!ctx || groups < 0 || groups > kMaxGroups) return SWK_ERR_ARG;
+    ctx->ialm_groups = groups;
     return SWK_OK;
 }
 
@@ -457,7 +549,9 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         rc = copy_out(ctx, out->opened, dOpen, plane, out->mem); if (rc) return rc;
         rc = copy_out(ctx, out->labels, dLab, plane, out->mem); if (rc) return rc;
     }
-    return sync(ctx);
+    rc = sync(ctx);
+    if (rc) return rc;
+    return gather_iters(ctx, dev_out ? nullptr : out->iters, dev_out ? out->iters : nullptr);
 }
 
 // ---- stage-level entry points (host buffers) ----------------------------------------
@@ -496,7 +590,9 @@ int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P, doub
         HIPCHK(ctx, hipMemcpyAsync(dst, pn, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return sync(ctx);
+    rc = sync(ctx);
+    if (rc) return rc;
+    return gather_iters(ctx, iters, nullptr);
 }
 
 int32_t swk_rpca_epilogue(swk_ctx *ctx, const double *E, int64_t count, uint8_t *S)
