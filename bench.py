@@ -35,11 +35,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=32, help="64-frame windows per step per GPU")
+    ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
+    ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1, help="windows in the CPU baseline sample")
     ap.add_argument("--host-input", action="store_true", help="also time a step fed from host memory (PCIe inclusive)")
@@ -104,6 +105,7 @@ def main():
     ctx = _lib.Context(local, nwin, n, Hc, Wc)
     ctx.set_ialm_variant(args.variant)
     ctx.set_ialm_groups(args.groups)
+    ctx.set_eig_cus(args.eig_cus)
     params = _lib.default_params()
     inp = _lib.Input(frames=frames.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
                      x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)

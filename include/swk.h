@@ -188,6 +188,10 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
 /* Window groups whose eigen-solves overlap the other groups' streaming passes:
  * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */
 int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);
+/* Reserve `cus` compute units for the eigen-solve side streams (CU-masked HIP streams); the
+ * streaming kernels then use the remaining ones.  -1 = auto (default), 0 = no partition.  Call before
+ * the first batch. */
+int32_t swk_set_eig_cus(swk_ctx *ctx, int32_t cus);
 
 #ifdef __cplusplus
 }

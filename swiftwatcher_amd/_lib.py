@@ -85,6 +85,7 @@ _SIGS = {
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -179,6 +180,9 @@ class Context:
 
     def set_ialm_groups(self, groups):
         self._check(self._lib.swk_set_ialm_groups(self._h, int(groups)))
+
+    def set_eig_cus(self, cus):
+        self._check(self._lib.swk_set_eig_cus(self._h, int(cus)))
 
     # ---- hot path ----
     def batch_run_raw(self, inp, params, out):

@@ -372,11 +372,11 @@ int ialm_pass_nblk(int variant, int n, int P, int nwin)
 {
     (void)n;
     if (variant == 2) {
-        // 256-thread blocks, one resident per CU (the n = 64 kernel takes the whole register file).
+        // 256-thread blocks, two resident per CU (LDS and registers).
         // Several rounds of blocks per CU keep the tail short when a few CUs are busy with another
         // group's eigen-solve; the cap bounds the Gram partial slabs (nblk x n^2 doubles per window).
         const int ntiles = (P + 15) / 16;
-        int per_win = (256 * 4 + nwin - 1) / nwin;
+        int per_win = (256 * 2 * 3 + nwin - 1) / nwin;   // two blocks resident per CU, three rounds
         const int cap = (ntiles + 7) / 8;          // at least two tiles per wave
         if (per_win > cap) per_win = cap;
         if (per_win > 128) per_win = 128;

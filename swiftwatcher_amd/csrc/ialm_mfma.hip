@@ -48,8 +48,34 @@ struct V2Cfg {
     static constexpr size_t lds_bytes = (size_t)(NPAD * BP + 4 * NPAD * TP) * sizeof(double);
 };
 
+typedef int v2i __attribute__((ext_vector_type(2)));
+constexpr unsigned kOob = 0x80000000u;        // a byte offset past every buffer: loads give 0, stores are dropped
+
+__device__ __forceinline__ double buf_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ int buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st8(int v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff, soff, 0);
+}
+
+// Two waves per SIMD (<= 256 registers): while one wave is in a matrix phase the other runs its
+// element-wise phase or waits for memory.  Every global access is a buffer instruction: the per-lane
+// byte offset is computed once per tile, the per-frame-row step is a wave-uniform SGPR offset, and the
+// hardware range check replaces all predication -- lanes past the last pixel (and X/S rows past the last
+// frame) get an out-of-range offset, so their loads read 0 and their stores vanish; zeros flow through
+// the arithmetic as zeros (A = Y = E = M = 0), which is exactly what padding must contribute.
 template <int NB, int MODE, bool WRITE_E>
-__global__ __launch_bounds__(256, 1) void k_ialm_pass_v2(IalmBuffers b)
+__global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
 {
     using C = V2Cfg<NB>;
     constexpr int NPAD = C::NPAD, NK = C::NK, BP = C::BP, TP = C::TP;
@@ -61,18 +87,18 @@ __global__ __launch_bounds__(256, 1) void k_ialm_pass_v2(IalmBuffers b)
     const IalmWin &st = b.win[w];
     if (st.done) return;
     const int n = b.n, P = b.P;
-    const int64_t ps = b.pstride;
+    const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
     const double dual = st.dual_norm;
-    // A/Y/E hold NPAD-aligned frame counts per window (b.fpad planes): rows f >= n are never stored
-    // and whatever is loaded from them is discarded, so the f64 streams need no per-lane clamping and
-    // every address is  window base (SGPR) + 32-bit lane offset + wave-uniform row step.
-    const uint8_t *X = b.X + (int64_t)w * n * P;
-    uint8_t *S = b.S + (int64_t)w * n * P;
-    double *A = b.A + (int64_t)w * b.fpad * ps, *Y = b.Y + (int64_t)w * b.fpad * ps;
-    double *Eo = WRITE_E ? b.E + (int64_t)w * b.fpad * ps : nullptr;
-    const unsigned ps32 = (unsigned)ps, P32 = (unsigned)P;
+    // A/Y/E hold b.fpad (n rounded up to 16) zero-initialised planes per window, X/S exactly n
+    const int fbytes = b.fpad * (int)ps32 * 8;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)(b.S + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)(b.A + (int64_t)w * b.fpad * b.pstride), 0, fbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void *)(b.Y + (int64_t)w * b.fpad * b.pstride), 0, fbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(WRITE_E ? b.E + (int64_t)w * b.fpad * b.pstride : b.A), 0, WRITE_E ? fbytes : 0, 0x00020000);
 
     if (MODE != 0) {
         const double *Bm = b.Bm + (int64_t)w * n * n;
@@ -84,70 +110,51 @@ __global__ __launch_bounds__(256, 1) void k_ialm_pass_v2(IalmBuffers b)
     __syncthreads();
 
     const int pl = lane & 15, fr0 = lane >> 4;
+    const int flim = n - fr0;                    // frame 4t + fr0 exists  <=>  4t < flim
     d4 G[C::NPAIR];
 #pragma unroll
     for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
     double zz = 0.0;
 
-    // One wave per SIMD (the kernel needs > 256 registers at n = 64), so HBM latency is hidden
-    // inside the wave: the raw X/A/Y values of the wave's NEXT tile are loaded into a second
-    // register set before the matrix work of the current tile starts.
     const int ntiles = (P + 15) >> 4;
-    const int tstride = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
-    int xn[NK];
-    double an[NK], yn[NK];
-    auto load_raw = [&](int tl) {
-        const int p_ = tl * 16 + pl;
-        const unsigned pc_ = (unsigned)(p_ < P ? p_ : P - 1);
-        const unsigned o64 = (unsigned)fr0 * ps32 + pc_;
-#pragma unroll
-        for (int t = 0; t < NK; ++t) {
-            const int f = 4 * t + fr0;
-            const unsigned fc = (unsigned)(f < n ? f : n - 1);
-            xn[t] = X[fc * P32 + pc_];
-            if (MODE == 2) {
-                an[t] = A[o64 + (unsigned)(4 * t) * ps32];
-                yn[t] = Y[o64 + (unsigned)(4 * t) * ps32];
-            }
-        }
-    };
-    if (tile < ntiles) load_raw(tile);
-    for (; tile < ntiles; tile += tstride) {
-        const int p = tile * 16 + pl;
-        const bool pvalid = p < P;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const unsigned p = (unsigned)(tile * 16 + pl);
+        const bool pvalid = p < P32;
+        const unsigned vo8 = pvalid ? ((unsigned)fr0 * ps32 + p) * 8u : kOob;     // f64 planes
+        const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
         int xi[NK];
-        double yv[NK], ev[NK], mv[NK];
-        // ---- finish-iteration element-wise part on the tile loaded one trip ago ----
+        double yv[NK], mv[NK];
+        // ---- loads (all in flight together), then the finish-iteration element-wise part ----
+        double av[NK];
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
-            const int f = 4 * t + fr0;
-            xi[t] = xn[t];
-            const double x = (double)xi[t];
+            xi[t] = buf_ld8(rX, 4 * t < flim ? vo1 : kOob, (unsigned)(4 * t) * P32);
             if (MODE == 2) {
-                yv[t] = yn[t];
-                const double raw = (x - an[t]) + inv_mu * yv[t];              // :282
-                ev[t] = shrink2(raw, thr);
-                mv[t] = (f < n) ? (x - ev[t]) + inv_mu * yv[t] : 0.0;          // :284
-            } else if (MODE == 1) {
-                yv[t] = x / dual;                                              // :272 (A = 0, :273)
-                const double raw = x + inv_mu * yv[t];
-                ev[t] = shrink2(raw, thr);
-                mv[t] = (f < n) ? (x - ev[t]) + inv_mu * yv[t] : 0.0;
+                av[t] = buf_ld64(rA, vo8, (unsigned)(4 * t) * ps32 * 8u);
+                yv[t] = buf_ld64(rY, vo8, (unsigned)(4 * t) * ps32 * 8u);
             }
         }
-        // ---- prefetch the next tile (clamped: the last trip re-reads a valid tile) ----
-        {
-            const int nt = tile + tstride;
-            load_raw(nt < ntiles ? nt : tile);
+        if (MODE != 0) {
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                const double x = (double)xi[t];
+                double raw;
+                if (MODE == 2) {
+                    raw = (x - av[t]) + inv_mu * yv[t];                        // :282
+                } else {
+                    yv[t] = x / dual;                                          // :272 (A = 0, :273)
+                    raw = x + inv_mu * yv[t];
+                }
+                const double e = shrink2(raw, thr);                            // :283
+                mv[t] = (x - e) + inv_mu * yv[t];                              // :284 (SVD input)
+                sT[(4 * t + fr0) * TP + pl] = e;        // parked in the cell M' of the same element will take
+            }
         }
         // ---- A_new^T = B^T M^T on the matrix cores, two out-frame blocks at a time (two independent
         //      accumulator chains), then Z, Y, stores and the start of the next iteration ----
 #pragma unroll
         for (int bq0 = 0; bq0 < NB; bq0 += 2) {
-            constexpr int kZero = 0;
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            (void)kZero;
             if (MODE != 0) {
 #pragma unroll
                 for (int t = 0; t < NK; ++t) {
@@ -166,30 +173,26 @@ __global__ __launch_bounds__(256, 1) void k_ialm_pass_v2(IalmBuffers b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = 4 * (bq0 + h) + r;
-                    const int f = 4 * t + fr0;
-                    const bool ok = pvalid && f < n;
                     const double x = (double)xi[t];
                     double a_new, y;
                     if (MODE == 0) {
                         a_new = 0.0;
                         y = x / dual;
                     } else {
+                        const double e = sT[(4 * t + fr0) * TP + pl];
                         a_new = acc[h][r];                                             // :290
-                        const double z = (x - a_new) - ev[t];                          // :293
+                        const double z = (x - a_new) - e;                              // :293
                         y = yv[t] + mu * z;                                            // :294
-                        if (ok) {
-                            zz += z * z;
-                            const unsigned o = (unsigned)fr0 * ps32 + (unsigned)p + (unsigned)(4 * t) * ps32;
-                            A[o] = a_new;
-                            Y[o] = y;
-                            S[(unsigned)f * P32 + (unsigned)p] = sparse_u8b(ev[t]);
-                            if (WRITE_E) Eo[o] = ev[t];
-                        }
+                        zz += z * z;
+                        const unsigned so8 = (unsigned)(4 * t) * ps32 * 8u;
+                        buf_st64(a_new, rA, vo8, so8);
+                        buf_st64(y, rY, vo8, so8);
+                        buf_st8((int)sparse_u8b(e), rS, 4 * t < flim ? vo1 : kOob, (unsigned)(4 * t) * P32);
+                        if (WRITE_E) buf_st64(e, rE, vo8, so8);
                     }
                     const double raw2 = (x - a_new) + inv_mu2 * y;
                     const double e2 = shrink2(raw2, thr2);
-                    const double m2 = ok ? (x - e2) + inv_mu2 * y : 0.0;
-                    sT[f * TP + pl] = m2;
+                    sT[(4 * t + fr0) * TP + pl] = (x - e2) + inv_mu2 * y;
                 }
             }
         }

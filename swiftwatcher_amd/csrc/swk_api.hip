@@ -45,6 +45,9 @@ struct swk_ctx {
     int64_t window_iters = 0;
     int ialm_variant = 0;
     int ialm_groups = 0;                 // 0 = auto
+    int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
+    int num_cus = 0;
+    bool stream_masked = false;
     hipStream_t gstream[8] = {nullptr};  // side streams of the IALM window groups
     hipEvent_t ev_pass[8] = {nullptr}, ev_small[8] = {nullptr}, ev_poll[8][2] = {{nullptr}};
     int ngroups_ready = 0;
@@ -117,9 +120,36 @@ struct Timed {
     }
 };
 
+// CU partition: the streaming kernels fill every CU they may use (two 256-thread blocks each take a
+// whole CU's registers), so a one-workgroup eigen-solve launched next to them would have to wait for
+// a CU to drain.  With eig_cus > 0 the main stream is confined to the first (num_cus - eig_cus) CUs and
+// the side streams to the last eig_cus, and both kinds of kernels always find room.
+void cu_mask(const swk_ctx *ctx, bool side, uint32_t *mask, int words)
+{
+    for (int i = 0; i < words; ++i) mask[i] = 0;
+    const int split = ctx->num_cus - ctx->eig_cus;
+    for (int cu = 0; cu < ctx->num_cus; ++cu)
+        if ((cu >= split) == side) mask[cu >> 5] |= 1u << (cu & 31);
+}
+
 int ensure_groups(swk_ctx *ctx, int ngroups)
 {
+    const int words = (ctx->num_cus + 31) / 32;
+    uint32_t mask[32];
+    if (ctx->eig_cus > 0 && !ctx->stream_masked) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hipStream_t ns;
+        cu_mask(ctx, false, mask, words);
+        HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ns, words, mask));
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->stream = ns;
+        ctx->stream_masked = true;
+    }
     for (int g = ctx->ngroups_ready; g < ngroups; ++g) {
+        if (ctx->eig_cus > 0) {
+            cu_mask(ctx, true, mask, words);
+            HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->gstream[g], words, mask));
+        } else
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream[g], hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pass[g], hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_small[g], hipEventDisableTiming));
@@ -208,7 +238,9 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     int variant = ctx->ialm_variant;
     if (variant == 0) variant = 2;
-    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : (nwin >= 16 ? 4 : (nwin >= 4 ? 2 : 1));
+    // auto: two groups once the batch is big enough for a group's passes to cover the other group's
+    // eigen-solves (measured: 2 groups + 32 reserved CUs best at 64..128 windows of 64 frames)
+    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : (nwin >= 8 ? 2 : 1);
     if (ngroups > kMaxGroups) ngroups = kMaxGroups;
     if (ngroups > nwin) ngroups = nwin;
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
@@ -234,6 +266,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
     // a window that stops before writing A (all-zero input) must still read back zeros
     HIPCHK(ctx, hipMemsetAsync(b.A, 0, felems * 8, s));
+    // padded frame planes (n..fpad-1) of Y are read by the MFMA pass and must contribute zeros
+    if (b.fpad != n) HIPCHK(ctx, hipMemsetAsync(b.Y, 0, felems * 8, s));
     if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, felems * 8, s));
 
     // Window groups.  The eigen-solve of a window runs on ONE compute unit for about a millisecond;
@@ -241,6 +275,12 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // cut into groups: all streaming passes go back to back on the main stream, each group's
     // small-matrix kernel goes on the group's side stream, and events tie pass_g(k) -> small_g(k) ->
     // pass_g(k+1).  While group g solves its eigenproblems the chip streams the other groups.
+    if (ctx->eig_cus < 0) {          // auto partition, decided once, at the first batch
+        int e = ngroups > 1 ? (nwin + 1) / 2 : 0;
+        if (e > 32) e = 32;
+        if (e > 0 && e < 8) e = 8;
+        ctx->eig_cus = e;
+    }
     int rc = ensure_groups(ctx, ngroups);
     if (rc) return rc;
     struct Group { IalmBuffers b; int w0; bool finished; };
@@ -369,6 +409,7 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
     if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SWK_ERR_HIP; }
     swk_ctx *ctx = new swk_ctx();
     ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_active, 256, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "stream / pinned memory creation failed";
@@ -456,6 +497,14 @@ int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups)
     return SWK_OK;
 }
 
+int32_t swk_set_eig_cus(swk_ctx *ctx, int32_t cus)
+{
+    if (!ctx || cus < -1 || cus > 128) return SWK_ERR_ARG;
+    if (ctx->ngroups_ready > 0 || ctx->stream_masked) return fail(ctx, SWK_ERR_ARG, "swk_set_eig_cus must be called before the first batch");
+    ctx->eig_cus = cus;
+    return SWK_OK;
+}
+
 // -------------------------------------------------------------------------------------
 int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, swk_output *out)
 {
@@ -513,15 +562,25 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
     CclBuffers cb{};
     rc = ensure_ccl(ctx, F, H, W, &cb);
     if (rc) return rc;
-    { Timed t(ctx, SWK_K_CCL); launch_ccl(s, dOpen, F, H, W, p->connectivity, p->label_order, cb, nullptr, dLab); }
-
-    if (out->segs || out->nseg) {
-        const int cap = out->segs ? out->seg_cap : 1;
-        swk_segment *dsegs; int32_t *dnseg;
+    const bool want_props = out->segs || out->nseg;
+    const int cap = out->segs ? out->seg_cap : 1;
+    swk_segment *dsegs = nullptr; int32_t *dnseg = nullptr;
+    if (want_props) {
         if (dev_out && out->segs) dsegs = out->segs; else NEED(ctx, SL_SEGS, (size_t)F * cap * sizeof(swk_segment), dsegs);
         if (dev_out && out->nseg) dnseg = out->nseg; else NEED(ctx, SL_NSEG, (size_t)F * 4, dnseg);
         HIPCHK(ctx, hipMemsetAsync(dsegs, 0, (size_t)F * cap * sizeof(swk_segment), s));
-        { Timed t(ctx, SWK_K_PROPS); launch_regionprops(s, dLab, F, H, W, cb, cap, dsegs, dnseg); }
+    }
+    const bool fused_ccl = ccl_frame_supported(H, W);
+    if (fused_ccl) {
+        // one workgroup per frame: labels and region properties in a single kernel
+        Timed t(ctx, SWK_K_CCL);
+        launch_ccl_frame(s, dOpen, F, H, W, p->connectivity, p->label_order, cb, nullptr, dLab, want_props, cap, dsegs, dnseg);
+    } else {
+        Timed t(ctx, SWK_K_CCL);
+        launch_ccl(s, dOpen, F, H, W, p->connectivity, p->label_order, cb, nullptr, dLab);
+    }
+    if (want_props) {
+        if (!fused_ccl) { Timed t(ctx, SWK_K_PROPS); launch_regionprops(s, dLab, F, H, W, cb, cap, dsegs, dnseg); }
         if (!dev_out) {
             rc = copy_out(ctx, out->segs, dsegs, (size_t)F * cap * sizeof(swk_segment), out->mem); if (rc) return rc;
             rc = copy_out(ctx, out->nseg, dnseg, (size_t)F * 4, out->mem); if (rc) return rc;
@@ -666,7 +725,10 @@ int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, i
     int rc = ensure_ccl(ctx, count, H, W, &cb);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(din, src, px, hipMemcpyHostToDevice, ctx->stream));
-    launch_ccl(ctx->stream, din, count, H, W, connectivity, label_order, cb, dlab, nullptr);
+    if (ccl_frame_supported(H, W))
+        launch_ccl_frame(ctx->stream, din, count, H, W, connectivity, label_order, cb, dlab, nullptr, false, 1, nullptr, nullptr);
+    else
+        launch_ccl(ctx->stream, din, count, H, W, connectivity, label_order, cb, dlab, nullptr);
     if (labels) HIPCHK(ctx, hipMemcpyAsync(labels, dlab, px * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ncomp) HIPCHK(ctx, hipMemcpyAsync(ncomp, cb.ncomp, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
     return sync(ctx);

@@ -79,6 +79,10 @@ void launch_ccl(hipStream_t s, const uint8_t *src, int F, int H, int W, int conn
                 const CclBuffers &b, int32_t *labels32 /*optional*/, uint8_t *labels8 /*optional*/);
 void launch_regionprops(hipStream_t s, const uint8_t *labels8, int F, int H, int W, const CclBuffers &b,
                         int seg_cap, swk_segment *segs, int32_t *nseg);
+// one-workgroup-per-frame fused labelling (+ region properties); needs the frame's bitmap in LDS
+bool ccl_frame_supported(int H, int W);
+void launch_ccl_frame(hipStream_t s, const uint8_t *src, int F, int H, int W, int connectivity, int order, const CclBuffers &b,
+                      int32_t *labels32, uint8_t *labels8, bool props, int seg_cap, swk_segment *segs, int32_t *nseg);
 size_t ccl_words(int H, int W);
 size_t ccl_padded(int H, int W);
 

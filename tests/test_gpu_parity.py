@@ -106,6 +106,16 @@ def test_ccl(ctx, orc, conn, order):
     np.testing.assert_array_equal(lab, ref)
 
 
+def test_ccl_large_frame_multi_kernel_path(ctx, orc):
+    """Frames too large for the one-workgroup-per-frame kernel's LDS bitmap take the multi-kernel path."""
+    rng = np.random.default_rng(8)
+    im = ((rng.random((800, 808)) < 0.3) * 255).astype(np.uint8)
+    n, lab = ctx.ccl_u8(im, 8, 1)
+    nref, ref = orc.ccl_u8(im, 8, 1)
+    assert n == nref
+    np.testing.assert_array_equal(lab, ref)
+
+
 def test_ccl_batch_more_than_255_components(ctx, orc):
     rng = np.random.default_rng(6)
     ims = ((rng.random((4, 80, 120)) < 0.2) * 200).astype(np.uint8)
