@@ -76,15 +76,11 @@ def main():
     import torch
     import torch.distributed as dist
     from swiftwatcher_amd import _lib, synthetic
+    from swiftwatcher_amd import distributed as swd
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    rank, world, local = swd.init("nccl")        # RCCL; no-op for a single process
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -120,8 +116,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        swd.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -140,16 +135,10 @@ def main():
     # ---- per-rank counts gathered over RCCL (the only collective of the path) ----
     it_host = iters.cpu().numpy()
     nseg_host = nseg.cpu().numpy()
-    counts = torch.tensor([F * args.steps, int(nseg_host.sum()), int(it_host.sum())], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        gathered = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(gathered, counts)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        total_frames = int(sum(int(g[0]) for g in gathered))
-    else:
-        total_frames = int(counts[0])
-    dt_max = float(tmax[0])
+    # every rank is one "video" here: (segments found, IALM iterations, frames processed)
+    table = swd.gather_counts({rank: (int(nseg_host.sum()), int(it_host.sum()), F * args.steps)}, world)
+    total_frames = int(table[:, 2].sum())
+    dt_max = swd.max_over_ranks(dt)
 
     if rank == 0:
         pass_ms, pass_launches = prof["ialm_pass"]
@@ -199,7 +188,7 @@ def main():
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
-        dist.barrier()
+        swd.barrier()
         dist.destroy_process_group()
 
 
