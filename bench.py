@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
+    ap.add_argument("--eig-method", type=int, default=0, help="0 Newton-Schulz (MFMA), 1 Jacobi")
     ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1, help="windows in the CPU baseline sample")
@@ -102,6 +103,7 @@ def main():
     ctx.set_ialm_variant(args.variant)
     ctx.set_ialm_groups(args.groups)
     ctx.set_eig_cus(args.eig_cus)
+    ctx.set_eig_method(args.eig_method)
     params = _lib.default_params()
     inp = _lib.Input(frames=frames.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
                      x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)

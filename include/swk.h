@@ -192,6 +192,9 @@ int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);
  * streaming kernels then use the remaining ones.  -1 = auto (default), 0 = no partition.  Call before
  * the first batch. */
 int32_t swk_set_eig_cus(swk_ctx *ctx, int32_t cus);
+/* G^(-1/2) of the n x n Gram matrix: 0 = coupled Newton-Schulz on the f64 matrix cores (default; falls back
+ * to Jacobi by itself if it does not converge), 1 = cyclic Jacobi eigen-solve. */
+int32_t swk_set_eig_method(swk_ctx *ctx, int32_t method);
 
 #ifdef __cplusplus
 }

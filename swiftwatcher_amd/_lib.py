@@ -86,6 +86,7 @@ _SIGS = {
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_set_eig_method": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -183,6 +184,9 @@ class Context:
 
     def set_eig_cus(self, cus):
         self._check(self._lib.swk_set_eig_cus(self._h, int(cus)))
+
+    def set_eig_method(self, method):
+        self._check(self._lib.swk_set_eig_method(self._h, int(method)))
 
     # ---- hot path ----
     def batch_run_raw(self, inp, params, out):

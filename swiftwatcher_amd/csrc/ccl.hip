@@ -164,38 +164,57 @@ void launch_ccl(hipStream_t s, const uint8_t *src, int F, int H, int W, int conn
 
 // ---------------------------------------------------------------------------------
 // Hot-path kernel: ONE workgroup per frame runs every phase of the labelling and the region
-// properties, separated by workgroup barriers instead of kernel boundaries:
-//   init -> union -> flatten + root bitmap -> bitmap prefix -> labels (+ region table) -> segment list.
-// The root bitmap, its per-word prefix and the 256-entry region table live in LDS; only the
-// union-find parents (touched for foreground pixels only) are in global memory, and stay in L2.
-// A frame is scanned 4 pixels per lane (one dword) when the row length allows it; the sparse image
-// makes most dwords zero and those cost one compare.
+// properties, separated by workgroup barriers instead of kernel boundaries.
+//
+// The unit of the union-find is the horizontal RUN (maximal row segment of foreground), not the
+// pixel: a sparse frame has a few hundred runs.  Two bitmaps in LDS describe the frame:
+//   fgr    one bit per pixel in raster order -> run start / run end / "next foreground pixel in the
+//          row above" are bit scans (clz / ffs) over one or two words;
+//   rsbits one bit per RUN START in the id order of the numbering rule (2x2-block or raster), so
+//          rank(run) = prefix popcount is monotone in the id, and the smallest id of a component is the
+//          smallest run rank in it -- the union-find root.  Final label = 1 + rank of the root among roots.
+// A run is joined to every run of the previous row it touches (8-way: columns cs-1..ce+1); region
+// properties are accumulated per run (area += length, column sum = arithmetic series).  Frames with more
+// than `cap` runs (noise) fall back to per-pixel union-find with parents in global memory.
 // ---------------------------------------------------------------------------------
 constexpr int kFrameThreads = 1024;
 
 struct FrameLds {
     int area[256], r0[256], c0[256], r1[256], c1[256];
     unsigned long long sr[256], sc[256];
-    int scan[kFrameThreads];
+    int scan[kFrameThreads / 64];
     int wave_tot[4];
 };
 
-template <int VEC, typename Fn>
-__device__ __forceinline__ void for_each_fg(const uint8_t *__restrict__ img, int P, Fn fn)
+template <int VEC> __device__ __forceinline__ uint32_t load_word(const uint8_t *img, int i)
 {
-    if (VEC == 4) {
-        const uint32_t *w32 = (const uint32_t *)img;
-        for (int i = threadIdx.x; i < (P >> 2); i += kFrameThreads) {
-            const uint32_t v = w32[i];
-            if (!v) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((v >> (8 * k)) & 0xffu) fn(4 * i + k);
-        }
-    } else {
-        for (int i = threadIdx.x; i < P; i += kFrameThreads)
-            if (img[i]) fn(i);
+    if (VEC == 4) return ((const uint32_t *)img)[i];
+    if (VEC == 2) return ((const uint16_t *)img)[i];
+    return img[i];
+}
+
+// fn(word index, VEC-byte word) over the frame, thread-strided; four loads in flight per trip
+template <int VEC, typename Fn>
+__device__ __forceinline__ void for_each_word(const uint8_t *__restrict__ img, int nwords, Fn fn)
+{
+    int i = threadIdx.x;
+    for (; i + 3 * kFrameThreads < nwords; i += 4 * kFrameThreads) {
+        const uint32_t a = load_word<VEC>(img, i), b = load_word<VEC>(img, i + kFrameThreads);
+        const uint32_t c = load_word<VEC>(img, i + 2 * kFrameThreads), d = load_word<VEC>(img, i + 3 * kFrameThreads);
+        fn(i, a); fn(i + kFrameThreads, b); fn(i + 2 * kFrameThreads, c); fn(i + 3 * kFrameThreads, d);
     }
+    for (; i < nwords; i += kFrameThreads) fn(i, load_word<VEC>(img, i));
+}
+
+template <int VEC, typename Fn>
+__device__ __forceinline__ void for_each_fg(const uint8_t *__restrict__ img, int nwords, Fn fn)
+{
+    for_each_word<VEC>(img, nwords, [&](int i, uint32_t v) {
+        if (!v) return;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            if ((v >> (8 * k)) & 0xffu) fn(VEC * i + k);
+    });
 }
 
 // block-wide exclusive prefix of popcounts over `nw` bitmap words; returns the total
@@ -206,7 +225,6 @@ __device__ __forceinline__ int bitmap_prefix(const uint32_t *bits, int nw, int *
     const int w0 = tid * per, w1 = w0 + per < nw ? w0 + per : nw;
     int cnt = 0;
     for (int w = w0; w < w1; ++w) cnt += __popc(bits[w]);
-    // wave-level inclusive scan, then the 16 wave totals
     int inc = cnt;
     const int lane = tid & 63, wv = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) {
@@ -241,10 +259,51 @@ __device__ __forceinline__ void lds_union(int *par, int a, int b)
     }
 }
 
-// The frame's foreground is compacted first: a bitmap over the id space + its prefix give every
-// foreground pixel a dense rank that is monotone in the id, so the whole union-find (parents, root
-// bitmap) fits in LDS and "smallest id" stays "smallest rank".  Frames with more foreground pixels
-// than `cap` fall back to parents in global memory (same results, slower).
+// ---- bit scans over the raster bitmap (bit b = pixel b of the frame) ----
+__device__ __forceinline__ uint32_t range_mask(int lo, int hi)          // bits lo..hi of a word, 0 <= lo <= hi <= 31
+{
+    return (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+}
+// first pixel of the run containing foreground pixel b; rb = first pixel of its row
+__device__ __forceinline__ int run_first(const uint32_t *fgr, int b, int rb)
+{
+    int pos = b;
+    for (;;) {
+        const int wi = pos >> 5, w0 = wi << 5;
+        const int lo = rb > w0 ? rb - w0 : 0;
+        const uint32_t inv = ~fgr[wi] & range_mask(lo, pos - w0);
+        if (inv) return w0 + (31 - __clz(inv)) + 1;
+        if (w0 <= rb) return rb;
+        pos = w0 - 1;
+    }
+}
+// last pixel of the run containing foreground pixel b; re = last pixel of its row
+__device__ __forceinline__ int run_last(const uint32_t *fgr, int b, int re)
+{
+    int pos = b;
+    for (;;) {
+        const int wi = pos >> 5, w0 = wi << 5;
+        const int hi = re < w0 + 31 ? re - w0 : 31;
+        const uint32_t inv = ~fgr[wi] & range_mask(pos - w0, hi);
+        if (inv) return w0 + __ffs(inv) - 2;
+        if (w0 + 31 >= re) return re;
+        pos = w0 + 32;
+    }
+}
+// first foreground pixel in [b, be], or -1
+__device__ __forceinline__ int next_fg(const uint32_t *fgr, int b, int be)
+{
+    int pos = b;
+    while (pos <= be) {
+        const int wi = pos >> 5, w0 = wi << 5;
+        const int hi = be < w0 + 31 ? be - w0 : 31;
+        const uint32_t m = fgr[wi] & range_mask(pos - w0, hi);
+        if (m) return w0 + __ffs(m) - 1;
+        pos = w0 + 32;
+    }
+    return -1;
+}
+
 template <int VEC, bool PROPS>
 __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__restrict__ src, int H, int W, int order, int conn8,
                                                              int *__restrict__ parent, int Pp, int words, int cap,
@@ -254,70 +313,120 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
 {
     extern __shared__ unsigned char lds_raw[];
     FrameLds *L = (FrameLds *)lds_raw;
-    uint32_t *fgbits = (uint32_t *)(lds_raw + sizeof(FrameLds));       // [words]  also the root bitmap of the global path
-    int *fgprefix = (int *)(fgbits + words);                            // [words]
-    int *cpar = fgprefix + words;                                       // [cap]    compact parents
-    uint32_t *rootbits = (uint32_t *)(cpar + cap);                      // [cap/32]
+    const int P = H * W, Wb = (W + 1) / 2, rwords = (P + 31) >> 5, nwords = P / VEC;
+    uint32_t *fgr = (uint32_t *)(lds_raw + sizeof(FrameLds));          // [rwords] raster foreground bitmap
+    uint32_t *rsbits = fgr + rwords;                                    // [words]  run starts, id order (roots in the fallback)
+    int *rsprefix = (int *)(rsbits + words);                            // [words]
+    int *run_rc = rsprefix + words;                                     // [cap]    row << 16 | first column
+    int *run_ce = run_rc + cap;                                         // [cap]    last column
+    int *cpar = run_ce + cap;                                           // [cap]    union-find parents over run ranks
+    int *rlab = cpar + cap;                                             // [cap]    final label of each run
+    uint32_t *rootbits = (uint32_t *)(rlab + cap);                      // [cap/32]
     int *rootprefix = (int *)(rootbits + cap / 32);                     // [cap/32]
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int P = H * W, Wb = (W + 1) / 2;
     const uint8_t *img = src + (int64_t)f * P;
     int *par = parent + (int64_t)f * Pp;
 
-    for (int i = tid; i < words; i += kFrameThreads) fgbits[i] = 0u;
+    for (int i = tid; i < rwords; i += kFrameThreads) fgr[i] = 0u;
+    for (int i = tid; i < words; i += kFrameThreads) rsbits[i] = 0u;
     for (int i = tid; i < cap / 32; i += kFrameThreads) rootbits[i] = 0u;
     if (PROPS && tid < 256) {
         L->area[tid] = 0; L->r0[tid] = INT_MAX; L->c0[tid] = INT_MAX; L->r1[tid] = -1; L->c1[tid] = -1;
         L->sr[tid] = 0; L->sc[tid] = 0;
     }
     __syncthreads();
-    for_each_fg<VEC>(img, P, [&](int idx) {
-        const int r = idx / W, c = idx - r * W;
-        const int id = pix_id(r, c, W, Wb, order);
-        atomicOr(&fgbits[id >> 5], 1u << (id & 31));
+    // ---- raster foreground bitmap: one LDS atomic per nonzero word ----
+    for_each_word<VEC>(img, nwords, [&](int i, uint32_t v) {
+        if (!v) return;
+        uint32_t nib = 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) nib |= ((v >> (8 * k)) & 0xffu) ? (1u << k) : 0u;
+        const int b = VEC * i;
+        atomicOr(&fgr[b >> 5], nib << (b & 31));
     });
     __syncthreads();
-    const int nfg = bitmap_prefix(fgbits, words, fgprefix, L->scan);
-    const bool compact = nfg <= cap;
-    auto rank_of = [&](int id) -> int { return fgprefix[id >> 5] + __popc(fgbits[id >> 5] & ((1u << (id & 31)) - 1u)); };
-
-    if (compact) {
-        for (int i = tid; i < nfg; i += kFrameThreads) cpar[i] = i;
-        __syncthreads();
-        for_each_fg<VEC>(img, P, [&](int idx) {
-            const int r = idx / W, c = idx - r * W;
-            const int me = rank_of(pix_id(r, c, W, Wb, order));
-            if (c > 0 && img[idx - 1]) lds_union(cpar, me, rank_of(pix_id(r, c - 1, W, Wb, order)));
-            if (r > 0) {
-                const uint8_t *up = img + idx - W;
-                if (up[0]) lds_union(cpar, me, rank_of(pix_id(r - 1, c, W, Wb, order)));
-                else if (conn8) {
-                    // with the pixel above set, NW and NE are already joined to it through their own W/E links
-                    if (c > 0 && up[-1]) lds_union(cpar, me, rank_of(pix_id(r - 1, c - 1, W, Wb, order)));
-                    if (c + 1 < W && up[1]) lds_union(cpar, me, rank_of(pix_id(r - 1, c + 1, W, Wb, order)));
-                }
+    // ---- run starts, in the id order of the numbering rule ----
+    auto for_each_run_start = [&](auto fn) {
+        for (int wi = tid; wi < rwords; wi += kFrameThreads) {
+            uint32_t m = fgr[wi];
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                const int b = (wi << 5) + bit;
+                const int r = b / W, c = b - r * W;
+                const bool start = c == 0 || !((fgr[(b - 1) >> 5] >> ((b - 1) & 31)) & 1u);
+                if (start) fn(b, r, c);
             }
+        }
+    };
+    for_each_run_start([&](int b, int r, int c) {
+        const int id = pix_id(r, c, W, Wb, order);
+        atomicOr(&rsbits[id >> 5], 1u << (id & 31));
+    });
+    __syncthreads();
+    const int nruns = bitmap_prefix(rsbits, words, rsprefix, L->scan);
+    const bool by_runs = nruns <= cap;
+    auto rank_of = [&](int id) -> int { return rsprefix[id >> 5] + __popc(rsbits[id >> 5] & ((1u << (id & 31)) - 1u)); };
+
+    if (by_runs) {
+        for_each_run_start([&](int b, int r, int c) {
+            const int run = rank_of(pix_id(r, c, W, Wb, order));
+            run_rc[run] = (r << 16) | c;
+            run_ce[run] = run_last(fgr, b, r * W + W - 1) - r * W;
+            cpar[run] = run;
         });
         __syncthreads();
-        for (int i = tid; i < nfg; i += kFrameThreads) {
-            const int root = lds_find(cpar, i);
-            if (root == i) atomicOr(&rootbits[i >> 5], 1u << (i & 31));
+        // ---- join every run with the runs it touches in the row above ----
+        for (int run = tid; run < nruns; run += kFrameThreads) {
+            const int r = run_rc[run] >> 16, cs = run_rc[run] & 0xffff, ce = run_ce[run];
+            if (r == 0) continue;
+            const int rb = (r - 1) * W, re = rb + W - 1;
+            int b = rb + (cs - conn8 > 0 ? cs - conn8 : 0);
+            const int be = rb + (ce + conn8 < W - 1 ? ce + conn8 : W - 1);
+            while (b <= be) {
+                const int hit = next_fg(fgr, b, be);
+                if (hit < 0) break;
+                const int us = run_first(fgr, hit, rb);
+                lds_union(cpar, run, rank_of(pix_id(r - 1, us - rb, W, Wb, order)));
+                b = run_last(fgr, hit, re) + 2;           // the pixel right after a run is background
+            }
         }
         __syncthreads();
-        // compress after every root is known (a concurrent find may still walk the old chains above)
-        for (int i = tid; i < nfg; i += kFrameThreads) cpar[i] = lds_find(cpar, i);
+        for (int i = tid; i < nruns; i += kFrameThreads)
+            if (lds_find(cpar, i) == i) atomicOr(&rootbits[i >> 5], 1u << (i & 31));
         __syncthreads();
-        const int nroots = bitmap_prefix(rootbits, (nfg + 31) >> 5, rootprefix, L->scan);
+        for (int i = tid; i < nruns; i += kFrameThreads) cpar[i] = lds_find(cpar, i);
+        __syncthreads();
+        const int nroots = bitmap_prefix(rootbits, (nruns + 31) >> 5, rootprefix, L->scan);
         if (ncomp && tid == 0) ncomp[f] = nroots;
+        // ---- label of every run; region properties per run ----
+        for (int run = tid; run < nruns; run += kFrameThreads) {
+            const int root = cpar[run];
+            const int label = rootprefix[root >> 5] + __popc(rootbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
+            rlab[run] = label;
+            if (PROPS) {
+                const int v = label & 0xff;                        // astype(np.uint8), image_filtering.py:329
+                if (v) {
+                    const int r = run_rc[run] >> 16, cs = run_rc[run] & 0xffff, ce = run_ce[run];
+                    const int len = ce - cs + 1;
+                    atomicAdd(&L->area[v], len);
+                    atomicMin(&L->r0[v], r); atomicMin(&L->c0[v], cs);
+                    atomicMax(&L->r1[v], r); atomicMax(&L->c1[v], ce);
+                    atomicAdd(&L->sr[v], (unsigned long long)r * (unsigned long long)len);
+                    atomicAdd(&L->sc[v], ((unsigned long long)(cs + ce) * (unsigned long long)len) >> 1);
+                }
+            }
+        }
+        __syncthreads();
     } else {
-        // ---- global-memory parents (dense frames) ----
-        for_each_fg<VEC>(img, P, [&](int idx) {
+        // ---- dense frame: per-pixel union-find, parents in global memory ----
+        for_each_fg<VEC>(img, nwords, [&](int idx) {
             const int r = idx / W, c = idx - r * W;
             const int id = pix_id(r, c, W, Wb, order);
             par[id] = id;
         });
         __syncthreads();
-        for_each_fg<VEC>(img, P, [&](int idx) {
+        for_each_fg<VEC>(img, nwords, [&](int idx) {
             const int r = idx / W, c = idx - r * W;
             const int id = pix_id(r, c, W, Wb, order);
             if (c > 0 && img[idx - 1]) uf_union(par, id, pix_id(r, c - 1, W, Wb, order));
@@ -325,45 +434,43 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
                 const uint8_t *up = img + idx - W;
                 if (up[0]) uf_union(par, id, pix_id(r - 1, c, W, Wb, order));
                 else if (conn8) {
+                    // with the pixel above set, NW and NE are already joined to it through their own W/E links
                     if (c > 0 && up[-1]) uf_union(par, id, pix_id(r - 1, c - 1, W, Wb, order));
                     if (c + 1 < W && up[1]) uf_union(par, id, pix_id(r - 1, c + 1, W, Wb, order));
                 }
             }
         });
         __syncthreads();
-        // the foreground bitmap is no longer needed: turn it into the root bitmap
-        for (int i = tid; i < words; i += kFrameThreads) fgbits[i] = 0u;
+        for (int i = tid; i < words; i += kFrameThreads) rsbits[i] = 0u;       // becomes the root bitmap
         __syncthreads();
-        for_each_fg<VEC>(img, P, [&](int idx) {
+        for_each_fg<VEC>(img, nwords, [&](int idx) {
             const int r = idx / W, c = idx - r * W;
             const int id = pix_id(r, c, W, Wb, order);
             const int root = uf_find(par, id);
-            if (root == id) atomicOr(&fgbits[id >> 5], 1u << (id & 31));
+            if (root == id) atomicOr(&rsbits[id >> 5], 1u << (id & 31));
             else __hip_atomic_store(&par[id], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         });
         __syncthreads();
-        const int nroots = bitmap_prefix(fgbits, words, fgprefix, L->scan);
+        const int nroots = bitmap_prefix(rsbits, words, rsprefix, L->scan);
         if (ncomp && tid == 0) ncomp[f] = nroots;
     }
-    // ---- labels for every pixel, region table for the foreground ----
+    // ---- label plane ----
     auto label_of = [&](int idx) -> int {
         const int r = idx / W, c = idx - r * W;
-        const int id = pix_id(r, c, W, Wb, order);
-        int label;
-        if (compact) {
-            const int root = cpar[rank_of(id)];
-            label = rootprefix[root >> 5] + __popc(rootbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
-        } else {
-            int root = __hip_atomic_load(&par[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (;;) {
-                const int q = __hip_atomic_load(&par[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q == root) break;
-                root = q;
-            }
-            label = fgprefix[root >> 5] + __popc(fgbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
+        if (by_runs) {
+            const int us = run_first(fgr, idx, r * W) - r * W;
+            return rlab[rank_of(pix_id(r, us, W, Wb, order))];
         }
+        const int id = pix_id(r, c, W, Wb, order);
+        int root = __hip_atomic_load(&par[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const int q = __hip_atomic_load(&par[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == root) break;
+            root = q;
+        }
+        const int label = rsprefix[root >> 5] + __popc(rsbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
         if (PROPS) {
-            const int v = label & 0xff;                        // astype(np.uint8), image_filtering.py:329
+            const int v = label & 0xff;
             if (v) {
                 atomicAdd(&L->area[v], 1);
                 atomicMin(&L->r0[v], r); atomicMin(&L->c0[v], c);
@@ -374,38 +481,33 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
         }
         return label;
     };
-    if (VEC == 4) {
-        const uint32_t *w32 = (const uint32_t *)img;
-        for (int i = tid; i < (P >> 2); i += kFrameThreads) {
-            const uint32_t v = w32[i];
-            uint32_t packed = 0;
-            int lab[4] = {0, 0, 0, 0};
-            if (v) {
+    for_each_word<VEC>(img, nwords, [&](int i, uint32_t v) {
+        uint32_t packed = 0;
+        int lab[VEC];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((v >> (8 * k)) & 0xffu) { lab[k] = label_of(4 * i + k); packed |= (uint32_t)(lab[k] & 0xff) << (8 * k); }
-            }
-            if (labels8) ((uint32_t *)(labels8 + (int64_t)f * P))[i] = packed;
-            if (labels32) {
-                int32_t *o = labels32 + (int64_t)f * P + 4 * i;
-                o[0] = lab[0]; o[1] = lab[1]; o[2] = lab[2]; o[3] = lab[3];
-            }
+        for (int k = 0; k < VEC; ++k) {
+            lab[k] = ((v >> (8 * k)) & 0xffu) ? label_of(VEC * i + k) : 0;
+            packed |= (uint32_t)(lab[k] & 0xff) << (8 * k);
         }
-    } else {
-        for (int i = tid; i < P; i += kFrameThreads) {
-            const int lab = img[i] ? label_of(i) : 0;
-            if (labels8) labels8[(int64_t)f * P + i] = (uint8_t)(lab & 0xff);
-            if (labels32) labels32[(int64_t)f * P + i] = lab;
+        if (labels8) {
+            uint8_t *o = labels8 + (int64_t)f * P;
+            if (VEC == 4) ((uint32_t *)o)[i] = packed;
+            else if (VEC == 2) ((uint16_t *)o)[i] = (uint16_t)packed;
+            else o[i] = (uint8_t)packed;
         }
-    }
+        if (labels32) {
+            int32_t *o = labels32 + (int64_t)f * P + VEC * i;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = lab[k];
+        }
+    });
     if (!PROPS) return;
     __syncthreads();
     // ---- ascending-label segment list ----
     if (tid < 256) {
         const bool live = tid > 0 && L->area[tid] > 0;
         const unsigned long long mask = __ballot(live);
-        const int lane = tid & 63, wv = tid >> 6;
-        if (lane == 0) L->wave_tot[wv] = __popcll(mask);
+        if ((tid & 63) == 0) L->wave_tot[tid >> 6] = __popcll(mask);
     }
     __syncthreads();
     if (tid < 256) {
@@ -426,9 +528,13 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     }
 }
 
-constexpr int kCompactCap = 8192;     // foreground pixels per frame handled with LDS-resident parents
-size_t ccl_frame_lds_bytes(int H, int W) { return sizeof(FrameLds) + ccl_words(H, W) * 8 + (size_t)kCompactCap * 4 + (kCompactCap / 32) * 8; }
-bool ccl_frame_supported(int H, int W) { return ccl_frame_lds_bytes(H, W) <= 150 * 1024; }
+constexpr int kRunCap = 2048;          // runs per frame handled in LDS
+size_t ccl_frame_lds_bytes(int H, int W)
+{
+    const size_t P = (size_t)H * W;
+    return sizeof(FrameLds) + ((P + 31) / 32) * 4 + ccl_words(H, W) * 8 + (size_t)kRunCap * 16 + (kRunCap / 32) * 8;
+}
+bool ccl_frame_supported(int H, int W) { return ccl_frame_lds_bytes(H, W) <= 150 * 1024 && H < 32768 && W < 65536; }
 
 template <int VEC, bool PROPS>
 static void launch_frame_t(hipStream_t s, const uint8_t *src, int F, int H, int W, int order, int conn8, const CclBuffers &b,
@@ -441,7 +547,15 @@ static void launch_frame_t(hipStream_t s, const uint8_t *src, int F, int H, int 
         attr_bytes = lds;
     }
     hipLaunchKernelGGL((k_ccl_frame<VEC, PROPS>), dim3(F), dim3(kFrameThreads), lds, s, src, H, W, order, conn8, b.parent, b.Pp,
-                       b.words, kCompactCap, labels32, labels8, b.ncomp, seg_cap, segs, nseg);
+                       b.words, kRunCap, labels32, labels8, b.ncomp, seg_cap, segs, nseg);
+}
+
+template <int VEC>
+static void launch_frame_p(hipStream_t s, const uint8_t *src, int F, int H, int W, int order, int conn8, const CclBuffers &b,
+                           int32_t *labels32, uint8_t *labels8, bool props, int seg_cap, swk_segment *segs, int32_t *nseg)
+{
+    if (props) launch_frame_t<VEC, true>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
+    else launch_frame_t<VEC, false>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
 }
 
 void launch_ccl_frame(hipStream_t s, const uint8_t *src, int F, int H, int W, int connectivity, int order, const CclBuffers &b,
@@ -449,14 +563,11 @@ void launch_ccl_frame(hipStream_t s, const uint8_t *src, int F, int H, int W, in
 {
     if (connectivity == 4) order = SWK_ORDER_RASTER;
     const int conn8 = connectivity == 8;
-    const bool vec4 = (W % 4 == 0) && (((uintptr_t)src & 3) == 0) && (!labels8 || ((uintptr_t)labels8 & 3) == 0);
-    if (vec4) {
-        if (props) launch_frame_t<4, true>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
-        else launch_frame_t<4, false>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
-    } else {
-        if (props) launch_frame_t<1, true>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
-        else launch_frame_t<1, false>(s, src, F, H, W, order, conn8, b, labels32, labels8, seg_cap, segs, nseg);
-    }
+    const int P = H * W;
+    const uintptr_t align = (uintptr_t)src | (labels8 ? (uintptr_t)labels8 : 0);
+    if (P % 4 == 0 && align % 4 == 0) launch_frame_p<4>(s, src, F, H, W, order, conn8, b, labels32, labels8, props, seg_cap, segs, nseg);
+    else if (P % 2 == 0 && align % 2 == 0) launch_frame_p<2>(s, src, F, H, W, order, conn8, b, labels32, labels8, props, seg_cap, segs, nseg);
+    else launch_frame_p<1>(s, src, F, H, W, order, conn8, b, labels32, labels8, props, seg_cap, segs, nseg);
 }
 
 // ---------------------------------------------------------------------------------

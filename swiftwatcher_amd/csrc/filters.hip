@@ -33,9 +33,56 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ frames
     out[((int64_t)f * H + r) * W + c] = (uint8_t)y;
 }
 
+// 4 pixels per thread, threads flat over the ROI (no idle lanes at row ends); 12 source bytes as three
+// dwords when the row start allows it, one dword store.
+__global__ __launch_bounds__(256) void k_gray4(const uint8_t *__restrict__ frames, int64_t frame_stride, int64_t row_stride,
+                                               int x0, int y0, int H, int W, int mode, uint8_t *__restrict__ out)
+{
+    const int f = blockIdx.y;
+    const int wq = W >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * wq) return;
+    const int r = idx / wq, c = (idx - r * wq) << 2;
+    const uint8_t *src = frames + (int64_t)f * frame_stride + (int64_t)(y0 + r) * row_stride + (int64_t)(x0 + c) * 3;
+    uint32_t w0, w1, w2;
+    if (((uintptr_t)src & 3) == 0) {
+        const uint32_t *s32 = (const uint32_t *)src;
+        w0 = s32[0]; w1 = s32[1]; w2 = s32[2];
+    } else {
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = src[k];
+        w0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        w1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        w2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+    const uint32_t px[4][3] = {{w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u},
+                               {w0 >> 24, w1 & 255u, (w1 >> 8) & 255u},
+                               {(w1 >> 16) & 255u, w1 >> 24, w2 & 255u},
+                               {(w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24}};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t y = mode == SWK_GRAY_Q14 ? (px[k][0] * 1868u + px[k][1] * 9617u + px[k][2] * 4899u + (1u << 13)) >> 14
+                                                : (px[k][0] * 3735u + px[k][1] * 19235u + px[k][2] * 9798u + (1u << 14)) >> 15;
+        packed |= y << (8 * k);
+    }
+    *(uint32_t *)(out + ((int64_t)f * H + r) * W + c) = packed;
+}
+
 void launch_gray(hipStream_t s, const uint8_t *frames, int channels, int64_t frame_stride, int64_t row_stride,
                  int x0, int y0, int F, int H, int W, int gray_mode, uint8_t *out)
 {
+    if (channels == 3 && (W & 3) == 0 && ((uintptr_t)out & 3) == 0) {
+        const int groups = H * (W >> 2);
+        for (int f0 = 0; f0 < F; f0 += 32768) {
+            const int fc = F - f0 < 32768 ? F - f0 : 32768;
+            hipLaunchKernelGGL(k_gray4, dim3((groups + 255) / 256, fc), dim3(256), 0, s,
+                               frames + (int64_t)f0 * frame_stride, frame_stride, row_stride, x0, y0, H, W, gray_mode,
+                               out + (int64_t)f0 * H * W);
+        }
+        return;
+    }
     // grid.z is limited to 65535: split the frame range
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
@@ -197,15 +244,13 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
     __shared__ float s_sw[32];
     __shared__ int s_ofs[32];
     __shared__ int s_any;
+    __shared__ int s_row_any[kSH], s_col_any[kSW];
     const int f = blockIdx.z;
     const int r0 = blockIdx.y * kTH, c0 = blockIdx.x * kTW;
     const uint8_t *img = src + (int64_t)f * H * W;
     if (threadIdx.x == 0) s_any = 0;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cw[i] = color_w[i];
-    if (threadIdx.x < maxk) {
-        s_sw[threadIdx.x] = space_w[threadIdx.x];
-        s_ofs[threadIdx.x] = (int)tdr[threadIdx.x] * kSW + (int)tdc[threadIdx.x];
-    }
+    if (threadIdx.x < kSH) s_row_any[threadIdx.x] = 0;
+    if (threadIdx.x < kSW) s_col_any[threadIdx.x] = 0;
     __syncthreads();
     int any = 0;
     for (int i = threadIdx.x; i < kSH * kSW; i += blockDim.x) {
@@ -218,16 +263,45 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
         const uint8_t v = img[r * W + c];
         s_src[i] = v;
         any |= v;
+        if (v) { s_row_any[lr] = 1; s_col_any[lc] = 1; }
     }
     if (any) s_any = 1;
     __syncthreads();
     const bool nonzero = s_any != 0;
+    if (!nonzero) {
+        // the sparse image is zero over the whole tile and its halo: every stage outputs zero
+        for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
+            const int r = r0 + i / kTW, c = c0 + i % kTW;
+            if (r < H && c < W) {
+                const int64_t o = ((int64_t)f * H + r) * W + c;
+                if (bil_out) bil_out[o] = 0;
+                if (thr_out) thr_out[o] = 0;
+                open_out[o] = 0;
+            }
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cw[i] = color_w[i];
+    if (threadIdx.x < maxk) {
+        s_sw[threadIdx.x] = space_w[threadIdx.x];
+        s_ofs[threadIdx.x] = (int)tdr[threadIdx.x] * kSW + (int)tdc[threadIdx.x];
+    }
+    __syncthreads();
     // bilateral + threshold on the (32+4)x(64+4) ring, in-image cells only
     for (int i = threadIdx.x; i < kBH * kBW; i += blockDim.x) {
         const int lr = i / kBW, lc = i % kBW;
         const int r = r0 + lr - 2, c = c0 + lc - 2;
         uint8_t outv = 0;
-        if (nonzero && r >= 0 && r < H && c >= 0 && c < W) {
+        // a pixel whose 7x7 neighbourhood holds no nonzero source pixel filters to 0: skip it when the
+        // source rows lr..lr+6 or columns lc..lc+6 of the tile are all empty
+        bool live = false;
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            int ra = 0, ca = 0;
+#pragma unroll
+            for (int k = 0; k <= 2 * kR; ++k) { ra |= s_row_any[lr + k]; ca |= s_col_any[lc + k]; }
+            live = ra && ca;
+        }
+        if (live) {
             const int ctr = (lr + kR) * kSW + (lc + kR);
             const int v0 = s_src[ctr];
             float sum = 0.f, wsum = 0.f;
@@ -248,13 +322,6 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
         s_thr[i] = outv;
     }
     __syncthreads();
-    if (!nonzero) {
-        for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
-            const int r = r0 + i / kTW, c = c0 + i % kTW;
-            if (r < H && c < W) open_out[((int64_t)f * H + r) * W + c] = 0;
-        }
-        return;
-    }
     for (int i = threadIdx.x; i < (kTH + 2) * (kTW + 2); i += blockDim.x) {
         const int lr = i / (kTW + 2), lc = i % (kTW + 2);
         const int r = clampi(r0 + lr - 1, H), c = clampi(c0 + lc - 1, W);

@@ -198,156 +198,6 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
     }
 }
 
-// ---------------------------------------------------------------------------------
-// One workgroup (1024 threads) per window: convergence test, mu update, Gram reduction,
-// cyclic Jacobi eigen-solve of G (n x n, f64, in LDS), B = I - G^(-1/2)/mu.
-//
-// Jacobi with round-robin ordering: every round applies m/2 disjoint rotations.  A round is two
-// phases: (a) 32 lanes compute (c, s) of their pair; (b) G <- J^T G J is applied per 2x2 block
-// (rows of pair a, columns of pair b): each block only needs its own four entries and the two
-// rotations, so all (m/2)^2 blocks update in place, concurrently; V <- V J alongside.
-// ---------------------------------------------------------------------------------
-constexpr int kJac = 65;    // LDS row pitch of the n x n matrices
-constexpr int kSmallThreads = 1024;
-
-__device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, int &q)
-{
-    if (k == 0) { p = m - 1; q = r; }
-    else { p = (r + k) % (m - 1); q = (r - k + (m - 1)) % (m - 1); }
-    if (p > q) { int tmp = p; p = q; q = tmp; }
-}
-
-__global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter)
-{
-    __shared__ double G[kMaxN * kJac];
-    __shared__ double V[kMaxN * kJac];
-    __shared__ double red[kSmallThreads];
-    __shared__ double cs_c[kMaxN / 2], cs_s[kMaxN / 2];
-    __shared__ int pq_p[kMaxN / 2], pq_q[kMaxN / 2];
-    __shared__ double wgt[kMaxN];
-    __shared__ int s_rot;
-    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nblk = b.nblk;
-    IalmWin &st = b.win[w];
-    if (st.done) return;
-
-    if (k >= 1) {
-        double acc = 0.0;
-        for (int i = tid; i < nblk; i += kSmallThreads) acc += b.zzpart[(int64_t)w * nblk + i];
-        red[tid] = acc;
-        __syncthreads();
-        for (int s = kSmallThreads / 2; s; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
-        const double ratio = sqrt(red[0]) / st.dnorm;            // :297
-        if (ratio < tol || k >= maxiter) {
-            if (tid == 0) { st.iter = k; st.done = 1; atomicSub(b.active, 1); }
-            return;
-        }
-    }
-    IalmScal cur = st.nxt, nxt;
-    nxt.mu = cur.mu * 1.5;                                       // :295 (min(mu*rho, mu*1e7) == mu*rho)
-    nxt.inv_mu = 1.0 / nxt.mu;
-    nxt.thr = lmbda / nxt.mu;
-    __syncthreads();
-    if (tid == 0) { st.cur = cur; st.nxt = nxt; st.iter = k; }
-
-    // deterministic reduction of the per-block Gram partials
-    const double *gp = b.gpart + (int64_t)w * nblk * n * n;
-    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
-        double acc = 0.0;
-        const int i = idx / n, j = idx % n;
-        // the MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): mirror the rest
-        const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
-        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + src];
-        G[i * kJac + j] = acc;
-        V[i * kJac + j] = i == j ? 1.0 : 0.0;
-    }
-    if ((n & 1) && tid <= n) {                 // zero row/column at the dummy index of an odd n
-        G[n * kJac + tid] = 0.0;
-        G[tid * kJac + n] = 0.0;
-    }
-    __syncthreads();
-
-    const int m = n + (n & 1), half = m / 2;
-    int sweeps = 0;
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        if (tid == 0) s_rot = 0;
-        __syncthreads();
-        for (int r = 0; r < m - 1; ++r) {
-            if (tid < half) {
-                int p, q;
-                round_robin_pair(m, r, tid, p, q);
-                double c = 1.0, s = 0.0;
-                if (q < n) {
-                    const double gpq = G[p * kJac + q], gpp = G[p * kJac + p], gqq = G[q * kJac + q];
-                    if (gpq != 0.0 && fabs(gpq) > 1e-15 * sqrt(fabs(gpp * gqq))) {
-                        // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (gqq - gpp) / (2 gpq), without forming tau
-                        const double d = gqq - gpp, b2 = 2.0 * gpq;
-                        const double tt = (d >= 0.0 ? b2 : -b2) / (fabs(d) + sqrt(d * d + b2 * b2));
-                        c = 1.0 / sqrt(1.0 + tt * tt);
-                        s = tt * c;
-                        s_rot = 1;
-                    }
-                }
-                pq_p[tid] = p; pq_q[tid] = q; cs_c[tid] = c; cs_s[tid] = s;
-            }
-            __syncthreads();
-            // G <- J^T G J, one 2x2 block (pair a rows, pair b columns) per item
-            for (int idx = tid; idx < half * half; idx += kSmallThreads) {
-                const int ka = idx / half, kb = idx % half;
-                const double sa = cs_s[ka], sb = cs_s[kb];
-                if (sa == 0.0 && sb == 0.0) continue;
-                const double ca = cs_c[ka], cb = cs_c[kb];
-                const int pa = pq_p[ka], qa = pq_q[ka], pb = pq_p[kb], qb = pq_q[kb];
-                // (for odd n the dummy index n is a zero row/column of G: rotating it is harmless)
-                const double g00 = G[pa * kJac + pb], g01 = G[pa * kJac + qb];
-                const double g10 = G[qa * kJac + pb], g11 = G[qa * kJac + qb];
-                // rows: (p, q) <- (c p - s q, s p + c q)
-                const double r00 = ca * g00 - sa * g10, r01 = ca * g01 - sa * g11;
-                const double r10 = sa * g00 + ca * g10, r11 = sa * g01 + ca * g11;
-                // columns likewise
-                G[pa * kJac + pb] = cb * r00 - sb * r01;
-                G[pa * kJac + qb] = sb * r00 + cb * r01;
-                G[qa * kJac + pb] = cb * r10 - sb * r11;
-                G[qa * kJac + qb] = sb * r10 + cb * r11;
-            }
-            // V <- V J
-            for (int idx = tid; idx < n * half; idx += kSmallThreads) {
-                const int i = idx / half, kk = idx % half;
-                const double s = cs_s[kk];
-                if (s == 0.0) continue;
-                const double c = cs_c[kk];
-                const int p = pq_p[kk], q = pq_q[kk];
-                const double vp = V[i * kJac + p], vq = V[i * kJac + q];
-                V[i * kJac + p] = c * vp - s * vq;
-                V[i * kJac + q] = s * vp + c * vq;
-            }
-            __syncthreads();
-        }
-        ++sweeps;
-        const int rot = s_rot;
-        __syncthreads();
-        if (!rot) break;
-    }
-    // G^(-1/2) = V diag(lambda^-1/2) V^T; zero (null-frame) directions get weight 0
-    if (tid < 64) {
-        double lam = tid < n ? G[tid * kJac + tid] : 0.0;
-        double lmax = lam;
-        for (int off = 32; off; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
-        if (tid < n) wgt[tid] = lam > 1e-13 * lmax ? 1.0 / sqrt(lam) : 0.0;
-    }
-    __syncthreads();
-    double *Bm = b.Bm + (int64_t)w * n * n;
-    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
-        const int i = idx / n, j = idx % n;
-        double acc = 0.0;
-        for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
-        Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * acc;
-    }
-    if (tid == 0) st.sweeps = sweeps;
-}
-
 // planes [nwin][n][P] -> reference layout [nwin][P][n]
 __global__ void k_planes_to_pn(const double *__restrict__ planes, double *__restrict__ out, int n, int P, int64_t ps, int fpad)
 {
@@ -430,11 +280,6 @@ void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant
     if (mode == 0) launch_v1<0, false>(s, b);
     else if (mode == 1) { if (we) launch_v1<1, true>(s, b); else launch_v1<1, false>(s, b); }
     else { if (we) launch_v1<2, true>(s, b); else launch_v1<2, false>(s, b); }
-}
-
-void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter)
-{
-    hipLaunchKernelGGL(k_ialm_small, dim3(b.nwin), dim3(kSmallThreads), 0, s, b, k, lmbda, tol, maxiter);
 }
 
 void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad)

@@ -1,0 +1,344 @@
+// The small-matrix step of every IALM iteration, one workgroup (1024 threads) per window:
+// convergence test (image_filtering.py:297), mu <- 1.5 mu (:295), reduction of the per-block Gram
+// partials, W = G^(-1/2) of the n x n Gram matrix, B = I - W/mu for the next streaming pass.
+//
+// G^(-1/2) by the coupled Newton-Schulz iteration
+//     Y0 = G/s, Z0 = I;   T = (3I - Z Y)/2;   Y <- Y T,  Z <- T Z;      Z -> (G/s)^(-1/2)
+// (s = ||G||_F >= lambda_max, so every eigenvalue of Y0 lies in (0, 1] and the iteration converges,
+// x2.25 per step for the small ones, then quadratically).  It is nothing but 64x64x64 matrix products:
+// v_mfma_f64_16x16x4_f64 on operands in LDS.  The iterates are polynomials in G (symmetric, commuting)
+// only in exact arithmetic, and the iteration is stable only as long as the rounding errors stay of the
+// form a true product leaves: mirroring the upper triangle, or reading the left operand transposed
+// (both tried: cheaper, and both diverge once cond(G) is large), is not allowed -- every product is the
+// full NPAD x NPAD matrix product in the written order.  12-25 iterations of 3 products.
+// Zero rows of G (all-zero "null" frames, io_video.py:40-44) are decoupled by construction, iterate
+// as a unit diagonal, and get weight 0 at the end (null frames are excluded).
+// If the iteration has not reached the quadratic regime after 60 steps (numerically singular G) the
+// cyclic Jacobi eigen-solver below takes over; it also serves as the reference implementation
+// (swk_set_eig_method).
+#include "swk_internal.h"
+
+namespace swk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int kSmallThreads = 1024;
+constexpr int kJac = 65;              // LDS row pitch of the Jacobi matrices
+
+__device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, int &q)
+{
+    if (k == 0) { p = m - 1; q = r; }
+    else { p = (r + k) % (m - 1); q = (r - k + (m - 1)) % (m - 1); }
+    if (p > q) { int tmp = p; p = q; q = tmp; }
+}
+
+// Convergence test and scalar update.  Returns false when the window is (now) finished.
+__device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int k, double lmbda, double tol, int maxiter,
+                                               double *red, IalmScal &cur)
+{
+    const int tid = threadIdx.x, nblk = b.nblk;
+    IalmWin &st = b.win[w];
+    if (st.done) return false;
+    if (k >= 1) {
+        double acc = 0.0;
+        for (int i = tid; i < nblk; i += kSmallThreads) acc += b.zzpart[(int64_t)w * nblk + i];
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = kSmallThreads / 2; s; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double ratio = sqrt(red[0]) / st.dnorm;            // :297
+        if (ratio < tol || k >= maxiter) {
+            if (tid == 0) { st.iter = k; st.done = 1; atomicSub(b.active, 1); }
+            return false;
+        }
+    }
+    cur = st.nxt;
+    IalmScal nxt;
+    nxt.mu = cur.mu * 1.5;                                       // :295 (min(mu*rho, mu*1e7) == mu*rho)
+    nxt.inv_mu = 1.0 / nxt.mu;
+    nxt.thr = lmbda / nxt.mu;
+    __syncthreads();
+    if (tid == 0) { st.cur = cur; st.nxt = nxt; st.iter = k; }
+    return true;
+}
+
+// Deterministic reduction of the per-block Gram partials into an LDS matrix of the given pitch.
+// The MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): the rest is mirrored.
+__device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double *G, int pitch)
+{
+    const int n = b.n, nblk = b.nblk;
+    const double *gp = b.gpart + (int64_t)w * nblk * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += kSmallThreads) {
+        const int i = idx / n, j = idx - i * n;
+        const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
+        double acc = 0.0;
+        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + src];
+        G[i * pitch + j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Cyclic Jacobi, round-robin ordering: every round applies m/2 disjoint rotations, G <- J^T G J per 2x2
+// block in place, V <- V J alongside.  Leaves W = V diag(lambda^-1/2) V^T in Wout (pitch kJac);
+// eigenvalues below 1e-13 lambda_max get weight 0.
+// ---------------------------------------------------------------------------------
+__device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double2 *cs, int *pq, double *wgt, int *flag, int *sweeps_out)
+{
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < n * n; idx += kSmallThreads) { const int i = idx / n, j = idx - i * n; V[i * kJac + j] = i == j ? 1.0 : 0.0; }
+    if ((n & 1) && tid <= n) {                 // zero row/column at the dummy index of an odd n
+        G[n * kJac + tid] = 0.0;
+        G[tid * kJac + n] = 0.0;
+    }
+    __syncthreads();
+    const int m = n + (n & 1), half = m / 2;
+    int sweeps = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int r = 0; r < m - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                round_robin_pair(m, r, tid, p, q);
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double gpq = G[p * kJac + q], gpp = G[p * kJac + p], gqq = G[q * kJac + q];
+                    const double g2 = gpq * gpq, dd = fabs(gpp * gqq);
+                    if (gpq != 0.0 && g2 > 1e-30 * dd) {
+                        if (g2 > 1e-16 * dd) *flag = 1;
+                        // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (gqq - gpp) / (2 gpq), without forming tau
+                        const double d = gqq - gpp, b2 = 2.0 * gpq;
+                        const double tt = (d >= 0.0 ? b2 : -b2) / (fabs(d) + sqrt(d * d + b2 * b2));
+                        c = rsqrt(1.0 + tt * tt);
+                        s = tt * c;
+                    }
+                }
+                cs[tid] = make_double2(c, s);
+                pq[tid] = p | (q << 8);
+            }
+            __syncthreads();
+            for (int idx = tid; idx < half * half; idx += kSmallThreads) {
+                const int ka = idx / half, kb = idx - ka * half;
+                const double2 ra = cs[ka], rb = cs[kb];
+                if (ra.y == 0.0 && rb.y == 0.0) continue;
+                const int pqa = pq[ka], pqb = pq[kb];
+                const int pa = pqa & 255, qa = pqa >> 8, pb = pqb & 255, qb = pqb >> 8;
+                const double g00 = G[pa * kJac + pb], g01 = G[pa * kJac + qb];
+                const double g10 = G[qa * kJac + pb], g11 = G[qa * kJac + qb];
+                const double r00 = ra.x * g00 - ra.y * g10, r01 = ra.x * g01 - ra.y * g11;
+                const double r10 = ra.y * g00 + ra.x * g10, r11 = ra.y * g01 + ra.x * g11;
+                G[pa * kJac + pb] = rb.x * r00 - rb.y * r01;
+                G[pa * kJac + qb] = rb.y * r00 + rb.x * r01;
+                G[qa * kJac + pb] = rb.x * r10 - rb.y * r11;
+                G[qa * kJac + qb] = rb.y * r10 + rb.x * r11;
+            }
+            for (int idx = tid; idx < n * half; idx += kSmallThreads) {
+                const int i = idx / half, kk = idx - i * half;
+                const double2 rk = cs[kk];
+                if (rk.y == 0.0) continue;
+                const int pqk = pq[kk];
+                const int p = pqk & 255, q = pqk >> 8;
+                const double vp = V[i * kJac + p], vq = V[i * kJac + q];
+                V[i * kJac + p] = rk.x * vp - rk.y * vq;
+                V[i * kJac + q] = rk.y * vp + rk.x * vq;
+            }
+            __syncthreads();
+        }
+        ++sweeps;
+        const int big = *flag;
+        __syncthreads();
+        // quadratic convergence: every off-diagonal this sweep met was below 1e-8 (relative) before it was
+        // rotated, so the sweep leaves them near 1e-16
+        if (!big) break;
+    }
+    if (tid < 64) {
+        double lam = tid < n ? G[tid * kJac + tid] : 0.0;
+        double lmax = lam;
+        for (int off = 32; off; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+        if (tid < n) wgt[tid] = lam > 1e-13 * lmax ? 1.0 / sqrt(lam) : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+        const int i = idx / n, j = idx - i * n;
+        double acc = 0.0;
+        for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
+        Wout[i * kJac + j] = acc;
+    }
+    __syncthreads();
+    *sweeps_out = sweeps;
+}
+
+// ---------------------------------------------------------------------------------
+// 16x16 output tile (ti, tj) of L*R, L and R stored [NPAD][PITCH] row-major in LDS.
+// A operand: lane l holds L[16ti + (l&15)][4kk + (l>>4)]; B operand: R[4kk + (l>>4)][16tj + (l&15)].
+// PITCH = NPAD + 2 makes the A reads conflict-free (16 rows land 4 banks apart) and the B reads 2-way.
+// Result: lane l, component r <-> element (16ti + (l>>4) + 4r, 16tj + (l&15)).
+// ---------------------------------------------------------------------------------
+template <int NPAD, int PITCH>
+__device__ __forceinline__ d4 mm_tile(const double *L, const double *R, int ti, int tj, int lane)
+{
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int lo = lane & 15, hi = lane >> 4;
+    const double *lp = L + (16 * ti + lo) * PITCH + hi;
+    const double *rp = R + hi * PITCH + 16 * tj + lo;
+    double a[NPAD / 4], bb[NPAD / 4];
+#pragma unroll
+    for (int kk = 0; kk < NPAD / 4; ++kk) { a[kk] = lp[4 * kk]; bb[kk] = rp[4 * kk * PITCH]; }
+#pragma unroll
+    for (int kk = 0; kk < NPAD / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bb[kk], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int PITCH>
+__device__ __forceinline__ void store_tile(double *M, d4 v, int ti, int tj, int lane)
+{
+    const int col = 16 * tj + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(16 * ti + (lane >> 4) + 4 * r) * PITCH + col] = v[r];
+}
+
+template <int NB> struct NsCfg {
+    static constexpr int NPAD = 16 * NB;
+    static constexpr int PITCH = NPAD + 2;
+    static constexpr int NT = NB * NB;
+    static constexpr size_t mat = (size_t)NPAD * PITCH;
+    static constexpr size_t jac = (size_t)3 * kMaxN * kJac;                    // G, V, W of the fallback
+    static constexpr size_t doubles = (3 * mat > jac ? 3 * mat : jac) + kSmallThreads + 64 + kMaxN;
+    static constexpr size_t lds_bytes = doubles * sizeof(double) + 128 * sizeof(int);   // pq[32], flag, dead[64]
+};
+
+template <int NB>
+__global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter, int method)
+{
+    using C = NsCfg<NB>;
+    constexpr int NPAD = C::NPAD, PITCH = C::PITCH, NT = C::NT;
+    extern __shared__ double sm[];
+    double *Y = sm, *Z = sm + C::mat, *T = sm + 2 * C::mat;
+    double *red = sm + (3 * C::mat > C::jac ? 3 * C::mat : C::jac);        // [1024]
+    double2 *cs = (double2 *)(red + kSmallThreads);                           // [32]
+    double *wgt = red + kSmallThreads + 64;                                   // [64]
+    int *ints = (int *)(wgt + kMaxN);                                         // pq[32], flag, sweeps, dead mask...
+    const int w = blockIdx.x, tid = threadIdx.x, n = b.n;
+    const int lane = tid & 63, wave = tid >> 6;
+    IalmScal cur;
+    if (!small_prologue(b, w, k, lmbda, tol, maxiter, red, cur)) return;
+    double *Bm = b.Bm + (int64_t)w * n * n;
+    IalmWin &st = b.win[w];
+
+    bool need_jacobi = method == 1;
+    int ns_iters = 0;
+    if (!need_jacobi) {
+        // ---- Y = G (padded with zeros), Z = I ----
+        for (int idx = tid; idx < NPAD * PITCH; idx += kSmallThreads) { Y[idx] = 0.0; Z[idx] = 0.0; }
+        __syncthreads();
+        gram_reduce(b, w, Y, PITCH);
+        __syncthreads();
+        // s = ||G||_F (fixed-order reduction)
+        double acc = 0.0;
+        for (int idx = tid; idx < n * n; idx += kSmallThreads) { const double v = Y[(idx / n) * PITCH + idx % n]; acc += v * v; }
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = kSmallThreads / 2; s; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double sc = sqrt(red[0]) * (1.0 + 1e-12);
+        const double inv_sc = 1.0 / sc;
+        __syncthreads();
+        if (tid < NPAD) ints[40 + tid] = (tid >= n || Y[tid * PITCH + tid] == 0.0) ? 1 : 0;      // dead directions
+        __syncthreads();
+        for (int idx = tid; idx < NPAD * NPAD; idx += kSmallThreads) {
+            const int i = idx / NPAD, j = idx - i * NPAD;
+            const bool dead = ints[40 + i] || ints[40 + j];
+            Y[i * PITCH + j] = dead ? (i == j ? 1.0 : 0.0) : Y[i * PITCH + j] * inv_sc;
+            Z[i * PITCH + j] = i == j ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        bool final_step = false, converged = false;
+        for (int it = 0; it < 60; ++it) {
+            // phase 1: P = Z Y;  T = (3I - P)/2;  residual ||I - P||_F^2
+            double r2 = 0.0;
+            for (int t = wave; t < NT; t += kSmallThreads / 64) {
+                const int ti = t / NB, tj = t - ti * NB;
+                d4 p = mm_tile<NPAD, PITCH>(Z, Y, ti, tj, lane);
+                d4 tt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                    const double e = (row == col ? 1.0 : 0.0) - p[r];
+                    r2 += e * e;
+                    tt[r] = (row == col ? 1.0 : 0.0) + 0.5 * e;          // (3I - P)/2 = I + (I - P)/2
+                }
+                store_tile<PITCH>(T, tt, ti, tj, lane);
+            }
+            for (int off = 32; off; off >>= 1) r2 += __shfl_down(r2, off);
+            if (lane == 0) red[wave] = r2;
+            __syncthreads();
+            double res2 = 0.0;
+            for (int i = 0; i < kSmallThreads / 64; ++i) res2 += red[i];
+            // phase 2: Y T and T Z into registers (both read the old Y, Z), then write back
+            d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+            const int j0 = wave, j1 = wave + kSmallThreads / 64;
+            const int t0 = j0 % NT, t1 = j1 % NT;
+            const int ti0 = t0 / NB, tj0 = t0 - ti0 * NB, ti1 = t1 / NB, tj1 = t1 - ti1 * NB;
+            if (j0 < 2 * NT) o0 = j0 < NT ? mm_tile<NPAD, PITCH>(Y, T, ti0, tj0, lane) : mm_tile<NPAD, PITCH>(T, Z, ti0, tj0, lane);
+            if (j1 < 2 * NT) o1 = j1 < NT ? mm_tile<NPAD, PITCH>(Y, T, ti1, tj1, lane) : mm_tile<NPAD, PITCH>(T, Z, ti1, tj1, lane);
+            __syncthreads();
+            if (j0 < 2 * NT) store_tile<PITCH>(j0 < NT ? Y : Z, o0, ti0, tj0, lane);
+            if (j1 < 2 * NT) store_tile<PITCH>(j1 < NT ? Y : Z, o1, ti1, tj1, lane);
+            __syncthreads();
+            ns_iters = it + 1;
+            if (!(res2 == res2)) break;                                      // NaN: give up, Jacobi decides
+            if (final_step) { converged = true; break; }
+            if (res2 < 1e-8) final_step = true;                              // ||I - ZY|| < 1e-4: two more steps reach 1e-16
+        }
+        if (converged) {
+            const double wscale = 1.0 / sqrt(sc);
+            for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+                const int i = idx / n, j = idx - i * n;
+                const bool dead = ints[40 + i] || ints[40 + j];
+                const double wv = dead ? 0.0 : 0.5 * (Z[i * PITCH + j] + Z[j * PITCH + i]) * wscale;
+                Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * wv;
+            }
+            if (tid == 0) st.sweeps = ns_iters;
+            return;
+        }
+        need_jacobi = true;
+        __syncthreads();
+    }
+    // ---- Jacobi (reference method / fallback) ----
+    double *G = sm, *V = sm + kMaxN * kJac, *Wm = sm + 2 * kMaxN * kJac;
+    gram_reduce(b, w, G, kJac);
+    __syncthreads();
+    int sweeps = 0;
+    jacobi_invsqrt(G, V, Wm, n, cs, ints, wgt, ints + 36, &sweeps);
+    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+        const int i = idx / n, j = idx - i * n;
+        Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * Wm[i * kJac + j];
+    }
+    if (tid == 0) st.sweeps = 100 + sweeps;
+}
+
+template <int NB>
+static void launch_small_nb(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_ialm_small<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NsCfg<NB>::lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_ialm_small<NB>), dim3(b.nwin), dim3(kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda, tol, maxiter, method);
+}
+
+void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
+{
+    switch ((b.n + 15) / 16) {
+    case 1: launch_small_nb<1>(s, b, k, lmbda, tol, maxiter, method); break;
+    case 2: launch_small_nb<2>(s, b, k, lmbda, tol, maxiter, method); break;
+    case 3: launch_small_nb<3>(s, b, k, lmbda, tol, maxiter, method); break;
+    default: launch_small_nb<4>(s, b, k, lmbda, tol, maxiter, method); break;
+    }
+}
+
+}  // namespace swk

@@ -45,6 +45,7 @@ struct swk_ctx {
     int64_t window_iters = 0;
     int ialm_variant = 0;
     int ialm_groups = 0;                 // 0 = auto
+    int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
     int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
     int num_cus = 0;
     bool stream_masked = false;
@@ -238,9 +239,10 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     int variant = ctx->ialm_variant;
     if (variant == 0) variant = 2;
-    // auto: two groups once the batch is big enough for a group's passes to cover the other group's
-    // eigen-solves (measured: 2 groups + 32 reserved CUs best at 64..128 windows of 64 frames)
-    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : (nwin >= 8 ? 2 : 1);
+    // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
+    // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
+    // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
+    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : 1;
     if (ngroups > kMaxGroups) ngroups = kMaxGroups;
     if (ngroups > nwin) ngroups = nwin;
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
@@ -276,7 +278,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // small-matrix kernel goes on the group's side stream, and events tie pass_g(k) -> small_g(k) ->
     // pass_g(k+1).  While group g solves its eigenproblems the chip streams the other groups.
     if (ctx->eig_cus < 0) {          // auto partition, decided once, at the first batch
-        int e = ngroups > 1 ? (nwin + 1) / 2 : 0;
+        int e = (ngroups > 1 && ctx->eig_method == 1) ? (nwin + ngroups - 1) / ngroups : 0;
         if (e > 32) e = 32;
         if (e > 0 && e < 8) e = 8;
         ctx->eig_cus = e;
@@ -311,7 +313,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
-        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]); launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter); }
+        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]); launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], ctx->gstream[g]));
     }
     for (int k = 1; k <= maxiter + 2; ++k) {
@@ -333,7 +335,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
             hipStream_t gs = ctx->gstream[g];
             HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
-            { Timed t(ctx, SWK_K_IALM_SMALL, gs); launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter); }
+            { Timed t(ctx, SWK_K_IALM_SMALL, gs); launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
             HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
             if (k >= check_from) {
                 HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));
@@ -494,6 +496,13 @@ int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups)
 {
     if (!ctx || groups < 0 || groups > kMaxGroups) return SWK_ERR_ARG;
     ctx->ialm_groups = groups;
+    return SWK_OK;
+}
+
+int32_t swk_set_eig_method(swk_ctx *ctx, int32_t method)
+{
+    if (!ctx || method < 0 || method > 1) return SWK_ERR_ARG;
+    ctx->eig_method = method;
     return SWK_OK;
 }
 

@@ -42,7 +42,8 @@ struct IalmBuffers {
 void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant);
-void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter);
+// method: 0 = Newton-Schulz on the f64 matrix cores (Jacobi only as fallback), 1 = cyclic Jacobi
+void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);
 void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad);
 void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S);
 int  ialm_pass_nblk(int variant, int n, int P, int nwin);

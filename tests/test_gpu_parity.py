@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 ATOL_AE = 1e-5
 
 
-@pytest.fixture(scope="module", params=[2, 1], ids=["ialm_mfma", "ialm_lds"])
+@pytest.fixture(scope="module", params=[(2, 0), (1, 1), (2, 1)], ids=["mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi"])
 def ctx(request):
-    """Every test runs against both IALM pass kernels: 2 = MFMA f64 (the default), 1 = LDS/VALU."""
+    """Every test runs against both IALM pass kernels (2 = MFMA f64, the default; 1 = LDS/VALU) and both
+    G^(-1/2) solvers (0 = Newton-Schulz on MFMA, the default; 1 = cyclic Jacobi)."""
     from swiftwatcher_amd import _lib
     c = _lib.Context(0)
-    c.set_ialm_variant(request.param)
+    c.set_ialm_variant(request.param[0])
+    c.set_eig_method(request.param[1])
     yield c
     c.close()
 

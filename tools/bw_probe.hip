@@ -55,7 +55,7 @@ int main()
     hipMemset(A, 0, elems * 8); hipMemset(Y, 0, elems * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 3; ++mode)
-        for (int blocks : {256, 512, 1024, 2048, 4096}) {
+        for (int blocks : {4096, 8192, 16384, 32768}) {
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(e0);
