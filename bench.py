@@ -152,8 +152,10 @@ def main():
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_ialm_pass.json")
         if os.path.exists(pmc_file):
-            try:
-                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            try:       # PMC passes are separate rocprofv3 runs (tools/pmc_pass.sh); valid for the same n and ROI
+                pmc = json.load(open(pmc_file))
+                if pmc.get("n") == n and pmc.get("P") == P:
+                    traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
             except Exception:
                 traffic = None
         res = {

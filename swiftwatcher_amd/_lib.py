@@ -8,7 +8,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswk.so")
+LIB_PATH = os.environ.get("SWK_LIB", os.path.join(_HERE, "libswk.so"))     # SWK_LIB: A/B another build of the same ABI
 
 MEM_HOST, MEM_DEVICE = 0, 1
 ORDER_RASTER, ORDER_BLOCK2X2 = 0, 1

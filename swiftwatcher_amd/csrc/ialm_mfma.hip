@@ -74,7 +74,8 @@ __device__ __forceinline__ void buf_st8(int v, __amdgpu_buffer_rsrc_t r, unsigne
 // hardware range check replaces all predication -- lanes past the last pixel (and X/S rows past the last
 // frame) get an out-of-range offset, so their loads read 0 and their stores vanish; zeros flow through
 // the arithmetic as zeros (A = Y = E = M = 0), which is exactly what padding must contribute.
-template <int NB, int MODE, bool WRITE_E>
+// FULL: n == 16 NB, no padded frame rows (saves the per-row offset selects and their registers)
+template <int NB, int MODE, bool WRITE_E, bool FULL>
 __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
 {
     using C = V2Cfg<NB>;
@@ -128,10 +129,13 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
         double av[NK];
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
-            xi[t] = buf_ld8(rX, 4 * t < flim ? vo1 : kOob, (unsigned)(4 * t) * P32);
+            // frame rows past n (n not a multiple of 16) get the out-of-range offset too: they read 0 and
+            // are never stored, so padding costs no HBM traffic
+            const bool fvalid = FULL || 4 * t < flim;
+            xi[t] = buf_ld8(rX, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
             if (MODE == 2) {
-                av[t] = buf_ld64(rA, vo8, (unsigned)(4 * t) * ps32 * 8u);
-                yv[t] = buf_ld64(rY, vo8, (unsigned)(4 * t) * ps32 * 8u);
+                av[t] = buf_ld64(rA, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
+                yv[t] = buf_ld64(rY, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
             }
         }
         if (MODE != 0) {
@@ -185,10 +189,12 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
                         y = yv[t] + mu * z;                                            // :294
                         zz += z * z;
                         const unsigned so8 = (unsigned)(4 * t) * ps32 * 8u;
-                        buf_st64(a_new, rA, vo8, so8);
-                        buf_st64(y, rY, vo8, so8);
-                        buf_st8((int)sparse_u8b(e), rS, 4 * t < flim ? vo1 : kOob, (unsigned)(4 * t) * P32);
-                        if (WRITE_E) buf_st64(e, rE, vo8, so8);
+                        const bool fvalid = FULL || 4 * t < flim;
+                        const unsigned vo8t = fvalid ? vo8 : kOob;
+                        buf_st64(a_new, rA, vo8t, so8);
+                        buf_st64(y, rY, vo8t, so8);
+                        buf_st8((int)sparse_u8b(e), rS, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
+                        if (WRITE_E) buf_st64(e, rE, vo8t, so8);
                     }
                     const double raw2 = (x - a_new) + inv_mu2 * y;
                     const double e2 = shrink2(raw2, thr2);
@@ -252,16 +258,23 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
 
 bool ialm_v2_supported(int n) { return n >= 1 && n <= kMaxN; }
 
-template <int NB, int MODE, bool WE>
-static void launch_one(hipStream_t s, const IalmBuffers &b)
+template <int NB, int MODE, bool WE, bool FULL>
+static void launch_full(hipStream_t s, const IalmBuffers &b)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v2<NB, MODE, WE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v2<NB, MODE, WE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)V2Cfg<NB>::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ialm_pass_v2<NB, MODE, WE>), dim3(b.nblk, b.nwin), dim3(256), V2Cfg<NB>::lds_bytes, s, b);
+    hipLaunchKernelGGL((k_ialm_pass_v2<NB, MODE, WE, FULL>), dim3(b.nblk, b.nwin), dim3(256), V2Cfg<NB>::lds_bytes, s, b);
+}
+
+template <int NB, int MODE, bool WE>
+static void launch_one(hipStream_t s, const IalmBuffers &b)
+{
+    if (b.n == 16 * NB) launch_full<NB, MODE, WE, true>(s, b);
+    else launch_full<NB, MODE, WE, false>(s, b);
 }
 
 template <int NB>
