@@ -268,3 +268,103 @@ def test_framequeue_drop_in(orc):
             assert s.status is None and s.segment_history == []
     popped = q.pop_frame()
     assert popped.frame_number == 0 and q.frames_processed == 1
+
+
+# ------------------------------------------------------------------ parameter variants, errors, end-to-end loop
+@pytest.mark.parametrize("over", [dict(connectivity=4), dict(label_order=0), dict(bil_fma=1), dict(thresh=40),
+                                  dict(gray_mode=1), dict(lmbda=0.02, tol=0.01), dict(maxiter=5)])
+def test_window_parameter_variants(ctx, orc, over):
+    """Every swk_params field reaches the kernels: non-default values against the oracle run the same way."""
+    from swiftwatcher_amd import _lib, synthetic
+    roi = synthetic.roi_window(77, 21, 64, 100, birds=4, bird_len=(10, 15), bird_wid=(4, 7))
+    res = ctx.batch_run(roi, 1, 21, params=_lib.default_params(**over))
+    okw = dict(over)
+    if "bil_fma" in okw:
+        okw["bil_fma"] = bool(okw["bil_fma"])
+    ref = orc.window(roi, **okw)
+    for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+        np.testing.assert_array_equal(res[key], ref[key], err_msg="%s %r" % (key, over))
+    for i in range(21):
+        assert _segs(res, i) == _orc_segs(ref["segments"][i])
+    if "maxiter" in over:
+        assert res["iters"][0] == 5
+
+
+def test_odd_sizes_and_gray_input(ctx, orc):
+    """ROI sizes that defeat every vector path (odd width, odd pixel count), gray input passing through
+    convert_grayscale (image_filtering.py:193-194), and a window of a single frame pair."""
+    from swiftwatcher_amd import synthetic
+    # (sizes stay above P*n ~ 1.1e5, below which the reference itself is LAPACK-dependent: DESIGN.md section 2)
+    for n, Hc, Wc in [(9, 121, 183), (21, 67, 94), (2, 251, 231)]:
+        roi = synthetic.roi_window(300 + n, n, Hc, Wc, birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+        gray = np.stack([orc.bgr2gray(f) for f in roi])
+        res_c = ctx.batch_run(roi, 1, n)
+        res_g = ctx.batch_run(gray, 1, n)
+        ref = orc.window(roi)
+        for key in ("rpca", "opened", "labels"):
+            np.testing.assert_array_equal(res_c[key], ref[key], err_msg="%s %dx%dx%d" % (key, n, Hc, Wc))
+            np.testing.assert_array_equal(res_g[key], ref[key])
+        for i in range(n):
+            assert _segs(res_c, i) == _orc_segs(ref["segments"][i])
+
+
+def test_error_paths(ctx):
+    from swiftwatcher_amd import _lib
+    rng = np.random.default_rng(0)
+    with pytest.raises(_lib.SwkError):          # more than 64 frames per window
+        ctx.batch_run(rng.integers(0, 255, size=(65, 16, 16), dtype=np.uint8), 1, 65)
+    with pytest.raises(_lib.SwkError):          # only the (3, 3) opening exists
+        ctx.batch_run(rng.integers(0, 255, size=(4, 16, 16), dtype=np.uint8), 1, 4, params=_lib.default_params(open_kh=5))
+    with pytest.raises(_lib.SwkError):
+        ctx.batch_run(rng.integers(0, 255, size=(4, 16, 16), dtype=np.uint8), 1, 4, params=_lib.default_params(connectivity=6))
+    with pytest.raises(_lib.SwkError):          # ROI too small for the 7x7 bilateral support
+        ctx.batch_run(rng.integers(0, 255, size=(4, 3, 16), dtype=np.uint8), 1, 4)
+    with pytest.raises(ValueError):
+        ctx.batch_run(rng.integers(0, 255, size=(4, 16, 16), dtype=np.uint8), 1, 4, crop=(10, 10, 16, 16))
+    # the context survives errors
+    out = ctx.thresh_tozero_u8(np.arange(32, dtype=np.uint8), 15)
+    assert out[16] == 16 and out[15] == 0
+
+
+def test_counting_loop_over_a_clip(orc):
+    """The reference's per-video loop (__main__.py:71-98) over a synthetic clip whose length is not a multiple
+    of the queue size: windows of 21 frames, the last one padded with null frames (io_video.py:40-44).
+    Per-frame segment lists must equal the oracle's for every real frame; null frames are not counted."""
+    from swiftwatcher_amd import synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    crop_region = [(30, 20), (30 + 96, 20 + 64)]
+    total = 52                      # 2 full windows + 10 real frames
+    clip = synthetic.full_frames(4242, total, crop_region, frame_hw=(110, 160), birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+    clip = clip[::-1].copy()        # synthetic stacks are newest-first; a reader delivers oldest first
+    q = FrameQueue()
+    per_frame = {}
+    read = 0
+    while q.frames_processed < total:
+        frames, numbers, stamps = [], [], []
+        for _ in range(q.maxlen):                           # reader.get_n_frames(n): pads past the end
+            if read < total:
+                frames.append(clip[read]); numbers.append(read); stamps.append("t%d" % read)
+            else:
+                frames.append(np.zeros_like(clip[0])); numbers.append(-1); stamps.append("00:00:00.000")
+            read += 1
+        q.push_list_of_frames(frames, numbers, stamps)
+        q.preprocess_queue(crop_region, (300, 150))
+        q.segment_queue((24, 24), crop_region)
+        while not q.is_empty():
+            f = q.pop_frame()
+            if not f.null:
+                per_frame[f.frame_number] = [(s.label, s.bbox, s.centroid) for s in f.segments]
+            else:
+                assert f.segments == []                     # null frames are excluded from RPCA: nothing found
+    assert q.frames_processed == total and sorted(per_frame) == list(range(total))
+    # oracle, window by window, in queue order (newest first)
+    for w0 in range(0, total, 21):
+        idx = list(range(w0, min(w0 + 21, total)))
+        stack = [clip[i][20:84, 30:126] for i in idx] + [np.zeros((64, 96, 3), np.uint8)] * (21 - len(idx))
+        roi = np.ascontiguousarray(np.stack(stack[::-1]))
+        ref = orc.window(roi)
+        for pos, seglist in enumerate(ref["segments"]):
+            fn_ = w0 + 20 - pos
+            if fn_ < total and fn_ in idx:
+                assert per_frame[fn_] == [(s["label"], s["bbox"], s["centroid"]) for s in seglist], "frame %d" % fn_
+    assert sum(len(v) for v in per_frame.values()) > 50
