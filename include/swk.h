@@ -169,6 +169,16 @@ int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, i
 int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, int32_t H, int32_t W,
                            int32_t seg_cap, swk_segment *segs, int32_t *nseg);
 
+/* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
+ * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size
+ * n_prev + n_curr, row-major.  Centroids are (row, col) float64 pairs; prev_hist0 = centroid of the first
+ * segment in each previous segment's history (ignored where prev_has_hist is 0). */
+int32_t swk_track_costs(const double *prev_c, const double *prev_hist0, const uint8_t *prev_has_hist,
+                        const double *curr_c, int32_t n_prev, int32_t n_curr, double *cost);
+/* apply_hungarian_algorithm (segment_tracking.py:257-263): scipy.optimize.linear_sum_assignment's algorithm
+ * with its tie rule; col4row[i] = column assigned to row i (n_rows <= n_cols). */
+int32_t swk_lsap(const double *cost, int32_t n_rows, int32_t n_cols, int32_t *col4row);
+
 /* ---- measurement hooks -----------------------------------------------------------
  * With profiling on, every kernel launch of swk_batch_run is bracketed by HIP events on
  * the context's stream; swk_prof_get returns accumulated device time and launch count per

@@ -79,6 +79,8 @@ _SIGS = {
     "swk_grey_open3x3_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
@@ -301,6 +303,32 @@ class Context:
         self._check(self._lib.swk_regionprops_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], seg_cap,
                                                  _ptr(segs), _ptr(nseg)))
         return (segs[0, :nseg[0]], int(nseg[0])) if single else (segs, nseg)
+
+
+def track_costs(prev_c, prev_hist0, prev_has_hist, curr_c):
+    """swk_track_costs: (n_prev + n_curr)^2 float64 cost matrix (host-side, no GPU needed)."""
+    n_prev, n_curr = len(prev_c), len(curr_c)
+    n = n_prev + n_curr
+    pc = np.ascontiguousarray(prev_c, np.float64).reshape(n_prev, 2)
+    ph = np.ascontiguousarray(prev_hist0, np.float64).reshape(n_prev, 2)
+    hh = np.ascontiguousarray(prev_has_hist, np.uint8).reshape(n_prev)
+    cc = np.ascontiguousarray(curr_c, np.float64).reshape(n_curr, 2)
+    cost = np.empty((n, n), np.float64)
+    rc = load().swk_track_costs(_ptr(pc), _ptr(ph), _ptr(hh), _ptr(cc), n_prev, n_curr, _ptr(cost))
+    if rc:
+        raise SwkError("swk_track_costs failed (%d)" % rc)
+    return cost
+
+
+def lsap(cost):
+    """swk_lsap: column assigned to every row (same result as scipy.optimize.linear_sum_assignment)."""
+    cost = np.ascontiguousarray(cost, np.float64)
+    nr, nc = cost.shape
+    out = np.empty(nr, np.int32)
+    rc = load().swk_lsap(_ptr(cost), nr, nc, _ptr(out))
+    if rc:
+        raise SwkError("swk_lsap failed (%d)" % rc)
+    return out
 
 
 _default_ctx = {}

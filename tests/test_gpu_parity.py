@@ -368,3 +368,34 @@ def test_counting_loop_over_a_clip(orc):
             if fn_ < total and fn_ in idx:
                 assert per_frame[fn_] == [(s["label"], s["bbox"], s["centroid"]) for s in seglist], "frame %d" % fn_
     assert sum(len(v) for v in per_frame.values()) > 50
+
+
+def test_swift_count_on_a_clip_matches_cpu_pipeline(orc):
+    """Segments from the HIP path -> tracker -> events -> count, against the same tracker fed by the CPU
+    oracle's segments (the tracker itself is pinned to the reference's traces in tests/test_tracking_counts.py)."""
+    from swiftwatcher_amd import synthetic, pipeline
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd.segment_tracking import SegmentTracker
+    from swiftwatcher_amd.data_structures import Frame, Segment
+    from swiftwatcher_amd.image_filtering import RegionProps
+    crop_region = [(30, 20), (30 + 160, 20 + 96)]
+    total = 63
+    clip = synthetic.full_frames(77, total, crop_region, frame_hw=(140, 230), birds=4, bird_len=(10, 14), bird_wid=(4, 6))[::-1].copy()
+    roi_mask = np.zeros((96, 160), np.uint8)
+    roi_mask[40:, :] = 255
+    count, events = pipeline.count_swifts(list(clip), crop_region, roi_mask)
+    # CPU side: oracle windows -> identical bookkeeping
+    tracker = SegmentTracker(roi_mask)
+    for w0 in range(0, total, 21):
+        idx = list(range(w0, min(w0 + 21, total)))
+        stack = [clip[i][20:116, 30:190] for i in idx] + [np.zeros((96, 160, 3), np.uint8)] * (21 - len(idx))
+        ref = orc.window(np.ascontiguousarray(np.stack(stack[::-1])))
+        for pos in range(20, -1, -1):                       # oldest first
+            t = w0 + 20 - pos
+            fr = Frame(None, t if t < total else -1, "%010.3f" % (t / 30.0))
+            fr.segments = [Segment(RegionProps(s["label"], s["bbox"], s["centroid"], s["area"]), fr.frame_number, fr.timestamp, None)
+                           for s in ref["segments"][pos]]
+            tracker.step(fr)
+    assert [(e[-1].parent_frame_number, len(e)) for e in events] == [(e[-1].parent_frame_number, len(e)) for e in tracker.detected_events]
+    assert count == ec.count_swifts(tracker.detected_events)
+    assert len(events) >= 1

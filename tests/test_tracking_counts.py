@@ -1,0 +1,129 @@
+"""tracker + event classification -> swift count, against traces recorded from
+the reference's own SegmentTracker / classify_events (oracle/make_tracker_goldens.py).  Host logic: no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from swiftwatcher_amd import _lib
+from swiftwatcher_amd.data_structures import Frame
+from swiftwatcher_amd import segment_tracking as st
+from swiftwatcher_amd import event_classification as ec
+
+
+class _Seg:
+    def __init__(self, label, centroid, t):
+        self.label = label
+        self.centroid = centroid
+        self.status = None
+        self.segment_history = []
+        self.parent_frame_number = t
+        self.parent_timestamp = "ts%05d" % t
+        self.segment_image = None
+
+
+def _replay(g):
+    tracker = st.SegmentTracker(g["roi"])
+    counts, cents = g["counts"], g["centroids"]
+    off = 0
+    assigns = []
+    for t, k in enumerate(counts):
+        fr = Frame(None, t, "ts%05d" % t)
+        fr.segments = [_Seg(i + 1, (float(cents[off + i, 0]), float(cents[off + i, 1])), t) for i in range(int(k))]
+        off += int(k)
+        tracker.set_current_frame(fr)
+        a = st.apply_hungarian_algorithm(tracker.formulate_cost_matrix())
+        assigns.append(np.asarray(a, np.int64))
+        tracker.store_assignments(a)
+        tracker.link_matching_segments()
+        tracker.check_for_events()
+        tracker.cache_current_frame()
+    return tracker, assigns
+
+
+@pytest.mark.parametrize("name", ["tracker_a", "tracker_b", "tracker_sparse"])
+def test_tracker_and_counts_match_reference_traces(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    tracker, assigns = _replay(g)
+    exp = np.split(g["assign_flat"], np.cumsum(g["assign_len"])[:-1]) if len(g["assign_len"]) else []
+    assert len(assigns) == len(exp)
+    for t, (a, e) in enumerate(zip(assigns, exp)):
+        np.testing.assert_array_equal(a, e, err_msg="assignment of frame %d" % t)
+    events = tracker.detected_events
+    assert [e[-1].parent_frame_number for e in events] == list(g["ev_last_frame"])
+    assert [len(e) for e in events] == list(g["ev_len"])
+    np.testing.assert_array_equal(np.array([e[0].centroid for e in events]).reshape(-1, 2), g["ev_first"])
+    np.testing.assert_array_equal(np.array([e[-1].centroid for e in events]).reshape(-1, 2), g["ev_last"])
+    angles_all = [ec.compute_angle([s.centroid for s in e]) for e in events]
+    np.testing.assert_array_equal(np.array(angles_all), g["angles_all"])
+    res = ec.classify_events(events)
+    np.testing.assert_array_equal(np.array(res["angle"]), g["angles_kept"])
+    assert res["label"] == list(g["labels"])
+    assert float(res["mode"]) == float(g["mode"])
+    assert ec.count_swifts(events) == int(g["total"])
+
+
+def test_cost_matrix_matches_python_restatement():
+    """swk_track_costs against a scalar restatement of segment_tracking.py:179-254 (math / ** operators)."""
+    import math
+    import sys
+    rng = np.random.default_rng(0)
+    for n_prev, n_curr in [(0, 0), (0, 3), (4, 0), (5, 7), (12, 9)]:
+        pc = rng.uniform(0, 200, (n_prev, 2)); cc = rng.uniform(0, 200, (n_curr, 2))
+        h0 = rng.uniform(0, 200, (n_prev, 2)); hh = rng.integers(0, 2, n_prev).astype(np.uint8)
+        got = _lib.track_costs(pc, h0, hh, cc)
+        n = n_prev + n_curr
+        exp = np.ones((n, n)) + sys.float_info.epsilon
+        for i in range(n_prev):
+            for j in range(n_curr):
+                d = math.sqrt((pc[i, 0] - cc[j, 0]) ** 2 + (pc[i, 1] - cc[j, 1]) ** 2)
+                if hh[i]:
+                    old = math.degrees(math.atan2(h0[i, 0] - pc[i, 0], -1 * (h0[i, 1] - pc[i, 1])))
+                    new = math.degrees(math.atan2(pc[i, 0] - cc[j, 0], -1 * (pc[i, 1] - cc[j, 1])))
+                    diff = abs(new - old)
+                    diff = min(diff, 360 - diff)
+                    ac = 2 ** (diff - 90)
+                else:
+                    ac = 1
+                exp[i, j + n_prev] = 0.5 * 2 ** (d - 25) + 0.5 * ac
+        for i in range(n):
+            exp[i, i] = 1
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_lsap_ties_match_scipy():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(1)
+    for trial in range(600):
+        n = int(rng.integers(1, 16))
+        if trial % 3 == 0:
+            c = rng.random((n, n))
+        elif trial % 3 == 1:
+            c = rng.integers(0, 3, size=(n, n)).astype(float)
+        else:
+            c = np.ones((n, n)) + np.finfo(float).eps
+            np.fill_diagonal(c, 1.0)
+            k = n // 2
+            if k:
+                c[:k, k:2 * k] = rng.choice([0.3, 0.7, 1.0, 1.5], size=(k, k))
+        np.testing.assert_array_equal(_lib.lsap(c), linear_sum_assignment(c)[1])
+    # rectangular
+    c = rng.random((4, 9))
+    np.testing.assert_array_equal(_lib.lsap(c), linear_sum_assignment(c)[1])
+
+
+def test_empty_and_degenerate_streams():
+    roi = np.full((10, 10), 255, np.uint8)
+    tr = st.SegmentTracker(roi)
+    for t in range(3):
+        tr.step(Frame(None, t, "t"))
+    assert tr.detected_events == [] and ec.count_swifts([]) == 0
+    # one bird crossing and vanishing inside the ROI: exactly one event, path of all its positions
+    tr = st.SegmentTracker(roi)
+    for t in range(4):
+        fr = Frame(None, t, "t%d" % t)
+        fr.segments = [_Seg(1, (1.0 + 2 * t, 2.0 + t), t)]
+        tr.step(fr)
+    tr.step(Frame(None, 4, "t4"))
+    assert len(tr.detected_events) == 1 and len(tr.detected_events[0]) == 4
+    assert ec.count_swifts(tr.detected_events) in (0, 1)
