@@ -217,14 +217,17 @@ __device__ __forceinline__ void for_each_fg(const uint8_t *__restrict__ img, int
     });
 }
 
-// block-wide exclusive prefix of popcounts over `nw` bitmap words; returns the total
+// Block-wide exclusive prefix of popcounts over `nw` bitmap words, kept per group of kPfx words (the rank
+// lookup adds the popcounts of up to kPfx-1 words itself: 4x less LDS).  Returns the total.
+constexpr int kPfx = 4;
 __device__ __forceinline__ int bitmap_prefix(const uint32_t *bits, int nw, int *prefix, int *scan)
 {
     const int tid = threadIdx.x;
-    const int per = (nw + kFrameThreads - 1) / kFrameThreads;
-    const int w0 = tid * per, w1 = w0 + per < nw ? w0 + per : nw;
+    const int ng = (nw + kPfx - 1) / kPfx;                       // groups of kPfx words
+    const int per = (ng + kFrameThreads - 1) / kFrameThreads;    // groups per thread
+    const int g0 = tid * per, g1 = g0 + per < ng ? g0 + per : ng;
     int cnt = 0;
-    for (int w = w0; w < w1; ++w) cnt += __popc(bits[w]);
+    for (int w = g0 * kPfx; w < g1 * kPfx && w < nw; ++w) cnt += __popc(bits[w]);
     int inc = cnt;
     const int lane = tid & 63, wv = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) {
@@ -236,9 +239,21 @@ __device__ __forceinline__ int bitmap_prefix(const uint32_t *bits, int nw, int *
     int base = 0, total = 0;
     for (int i = 0; i < kFrameThreads / 64; ++i) { const int t = scan[i]; if (i < wv) base += t; total += t; }
     int run = base + inc - cnt;
-    for (int w = w0; w < w1; ++w) { prefix[w] = run; run += __popc(bits[w]); }
+    for (int g = g0; g < g1; ++g) {
+        prefix[g] = run;
+        for (int w = g * kPfx; w < (g + 1) * kPfx && w < nw; ++w) run += __popc(bits[w]);
+    }
     __syncthreads();
     return total;
+}
+
+// number of set bits below position `pos` of the bitmap, from the grouped prefix
+__device__ __forceinline__ int bitmap_rank(const uint32_t *bits, const int *prefix, int pos)
+{
+    const int w = pos >> 5, g = w / kPfx;
+    int r = prefix[g];
+    for (int k = g * kPfx; k < w; ++k) r += __popc(bits[k]);
+    return r + __popc(bits[w] & ((1u << (pos & 31)) - 1u));
 }
 
 __device__ __forceinline__ int lds_find(const int *par, int i)
@@ -316,8 +331,8 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     const int P = H * W, Wb = (W + 1) / 2, rwords = (P + 31) >> 5, nwords = P / VEC;
     uint32_t *fgr = (uint32_t *)(lds_raw + sizeof(FrameLds));          // [rwords] raster foreground bitmap
     uint32_t *rsbits = fgr + rwords;                                    // [words]  run starts, id order (roots in the fallback)
-    int *rsprefix = (int *)(rsbits + words);                            // [words]
-    int *run_rc = rsprefix + words;                                     // [cap]    row << 16 | first column
+    int *rsprefix = (int *)(rsbits + words);                            // [words / kPfx]
+    int *run_rc = rsprefix + (words + kPfx - 1) / kPfx;                 // [cap]    row << 16 | first column
     int *run_ce = run_rc + cap;                                         // [cap]    last column
     int *cpar = run_ce + cap;                                           // [cap]    union-find parents over run ranks
     int *rlab = cpar + cap;                                             // [cap]    final label of each run
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     __syncthreads();
     const int nruns = bitmap_prefix(rsbits, words, rsprefix, L->scan);
     const bool by_runs = nruns <= cap;
-    auto rank_of = [&](int id) -> int { return rsprefix[id >> 5] + __popc(rsbits[id >> 5] & ((1u << (id & 31)) - 1u)); };
+    auto rank_of = [&](int id) -> int { return bitmap_rank(rsbits, rsprefix, id); };
 
     if (by_runs) {
         for_each_run_start([&](int b, int r, int c) {
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
         // ---- label of every run; region properties per run ----
         for (int run = tid; run < nruns; run += kFrameThreads) {
             const int root = cpar[run];
-            const int label = rootprefix[root >> 5] + __popc(rootbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
+            const int label = bitmap_rank(rootbits, rootprefix, root) + 1;
             rlab[run] = label;
             if (PROPS) {
                 const int v = label & 0xff;                        // astype(np.uint8), image_filtering.py:329
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
             if (q == root) break;
             root = q;
         }
-        const int label = rsprefix[root >> 5] + __popc(rsbits[root >> 5] & ((1u << (root & 31)) - 1u)) + 1;
+        const int label = bitmap_rank(rsbits, rsprefix, root) + 1;
         if (PROPS) {
             const int v = label & 0xff;
             if (v) {
@@ -532,7 +547,8 @@ constexpr int kRunCap = 2048;          // runs per frame handled in LDS
 size_t ccl_frame_lds_bytes(int H, int W)
 {
     const size_t P = (size_t)H * W;
-    return sizeof(FrameLds) + ((P + 31) / 32) * 4 + ccl_words(H, W) * 8 + (size_t)kRunCap * 16 + (kRunCap / 32) * 8;
+    const size_t words = ccl_words(H, W);
+    return sizeof(FrameLds) + ((P + 31) / 32) * 4 + words * 4 + ((words + kPfx - 1) / kPfx) * 4 + (size_t)kRunCap * 16 + (kRunCap / 32) * 8;
 }
 bool ccl_frame_supported(int H, int W) { return ccl_frame_lds_bytes(H, W) <= 150 * 1024 && H < 32768 && W < 65536; }
 

@@ -198,6 +198,20 @@ def test_window_all_stages(ctx, orc, n, Hc, Wc, birds):
         assert _segs(res, i) == _orc_segs(ref["segments"][i])
 
 
+def test_4k_scale_roi(ctx, orc):
+    """P3 = 850x425 (the 4K scale-up of BASELINE config 5): every stage and the per-frame labelling kernel's
+    LDS bitmaps at that size, against the oracle."""
+    from swiftwatcher_amd import synthetic
+    roi = synthetic.roi_window(31, 7, 425, 850, birds=14, bird_len=(40, 70), bird_wid=(16, 28))
+    res = ctx.batch_run(roi, 1, 7)
+    ref = orc.window(roi)
+    for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+        np.testing.assert_array_equal(res[key], ref[key], err_msg=key)
+    for i in range(7):
+        assert _segs(res, i) == _orc_segs(ref["segments"][i])
+    assert int(res["nseg"].sum()) >= 1
+
+
 def test_batch_of_windows_with_crop_from_full_frames(ctx, orc):
     """Several windows per call, ROI cropped on the device side of the boundary from whole frames,
     different content per window (so per-window iteration counts may differ)."""
