@@ -81,7 +81,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    rank, world, local = swd.init("nccl")        # RCCL; no-op for a single process
+    # RCCL ("nccl" on ROCm); no-op for a single process.  SWK_DIST_BACKEND=gloo lets several ranks share one GPU
+    # for rehearsals (RCCL refuses two ranks on one device).
+    rank, world, local = swd.init(os.environ.get("SWK_DIST_BACKEND", "nccl"))
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -22,6 +22,7 @@ def init(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
         else:
