@@ -29,10 +29,25 @@ __global__ __launch_bounds__(256) void k_ialm_stats(const uint8_t *__restrict__ 
     const uint8_t *x = X + (int64_t)w * per_win;
     unsigned long long ss = 0;
     unsigned int mx = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_win; i += (int64_t)gridDim.x * blockDim.x) {
-        unsigned int v = x[i];
-        ss += v * v;
-        mx = v > mx ? v : mx;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (int64_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)x) & 3) == 0) {                         // dword path: 4 pixels per load
+        const uint32_t *x4 = (const uint32_t *)x;
+        const int64_t nq = per_win >> 2;
+        for (int64_t i = gtid; i < nq; i += gsize) {
+            const uint32_t v = x4[i];
+            const unsigned int a = v & 255u, b2 = (v >> 8) & 255u, c = (v >> 16) & 255u, d = v >> 24;
+            ss += a * a + b2 * b2 + c * c + d * d;
+            const unsigned int m01 = a > b2 ? a : b2, m23 = c > d ? c : d;
+            const unsigned int m = m01 > m23 ? m01 : m23;
+            mx = m > mx ? m : mx;
+        }
+        for (int64_t i = (nq << 2) + gtid; i < per_win; i += gsize) { const unsigned int v = x[i]; ss += v * v; mx = v > mx ? v : mx; }
+    } else {
+        for (int64_t i = gtid; i < per_win; i += gsize) {
+            unsigned int v = x[i];
+            ss += v * v;
+            mx = v > mx ? v : mx;
+        }
     }
     for (int off = 32; off; off >>= 1) {
         ss += __shfl_down(ss, off);

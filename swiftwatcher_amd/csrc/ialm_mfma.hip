@@ -45,7 +45,8 @@ struct V2Cfg {
     static constexpr int BP = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;   // LDS pitch of B: rows 32 banks apart
     static constexpr int TP = 17;                                 // LDS pitch of the transpose tile
     static constexpr int NPAIR = NB * (NB + 1) / 2;
-    static constexpr size_t lds_bytes = (size_t)(NPAD * BP + 4 * NPAD * TP) * sizeof(double);
+    // + 256 doubles: table of x / dual_norm for the 256 possible u8 values (first two passes)
+    static constexpr size_t lds_bytes = (size_t)(NPAD * BP + 4 * NPAD * TP + 256) * sizeof(double);
 };
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
     const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(WRITE_E ? b.E + (int64_t)w * b.fpad * b.pstride : b.A), 0, WRITE_E ? fbytes : 0, 0x00020000);
 
+    // Y0 = X / dual_norm (:272) takes one of 256 values: divide once per value, exactly, and look it up
+    double *sY0 = lds + NPAD * BP + 4 * NPAD * TP;
+    if (MODE != 2) sY0[tid] = (double)tid / dual;
     if (MODE != 0) {
         const double *Bm = b.Bm + (int64_t)w * n * n;
         for (int i = tid; i < NPAD * NPAD; i += 256) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
                 if (MODE == 2) {
                     raw = (x - av[t]) + inv_mu * yv[t];                        // :282
                 } else {
-                    yv[t] = x / dual;                                          // :272 (A = 0, :273)
+                    yv[t] = sY0[xi[t]];                                        // x / dual, :272 (A = 0, :273)
                     raw = x + inv_mu * yv[t];
                 }
                 const double e = shrink2(raw, thr);                            // :283
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
                     double a_new, y;
                     if (MODE == 0) {
                         a_new = 0.0;
-                        y = x / dual;
+                        y = sY0[xi[t]];
                     } else {
                         const double e = sT[(4 * t + fr0) * TP + pl];
                         a_new = acc[h][r];                                             // :290

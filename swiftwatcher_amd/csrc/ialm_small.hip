@@ -67,13 +67,13 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
 // The MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): the rest is mirrored.
 __device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double *G, int pitch)
 {
-    const int n = b.n, nblk = b.nblk;
+    const int n = b.n, nblk = b.nblk, nred = b.nred;
     const double *gp = b.gpart + (int64_t)w * nblk * n * n;
     for (int idx = threadIdx.x; idx < n * n; idx += kSmallThreads) {
         const int i = idx / n, j = idx - i * n;
         const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
         double acc = 0.0;
-        for (int bk = 0; bk < nblk; ++bk) acc += gp[(int64_t)bk * n * n + src];
+        for (int bk = 0; bk < nred; ++bk) acc += gp[(int64_t)bk * n * n + src];
         G[i * pitch + j] = acc;
     }
 }
@@ -178,7 +178,8 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
 template <int NPAD, int PITCH>
 __device__ __forceinline__ d4 mm_tile(const double *L, const double *R, int ti, int tj, int lane)
 {
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    // two accumulator chains (even / odd k-steps): a dependent f64 MFMA waits out the previous one's latency
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const int lo = lane & 15, hi = lane >> 4;
     const double *lp = L + (16 * ti + lo) * PITCH + hi;
     const double *rp = R + hi * PITCH + 16 * tj + lo;
@@ -186,8 +187,11 @@ __device__ __forceinline__ d4 mm_tile(const double *L, const double *R, int ti, 
 #pragma unroll
     for (int kk = 0; kk < NPAD / 4; ++kk) { a[kk] = lp[4 * kk]; bb[kk] = rp[4 * kk * PITCH]; }
 #pragma unroll
-    for (int kk = 0; kk < NPAD / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bb[kk], acc, 0, 0, 0);
-    return acc;
+    for (int kk = 0; kk < NPAD / 4; kk += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bb[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk + 1], bb[kk + 1], acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
 }
 
 template <int PITCH>
@@ -318,6 +322,25 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * Wm[i * kJac + j];
     }
     if (tid == 0) st.sweeps = 100 + sweeps;
+}
+
+// With many slabs per window (small batches use many blocks per window) the sum is done by the whole chip
+// first: one thread per matrix entry, slabs added in index order -> same result as the in-kernel loop.
+__global__ __launch_bounds__(256) void k_gram_reduce(IalmBuffers b)
+{
+    const int w = blockIdx.y, n = b.n;
+    if (b.win[w].done) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    double *gp = b.gpart + (int64_t)w * b.nblk * n * n;
+    double acc = 0.0;
+    for (int bk = 0; bk < b.nblk; ++bk) acc += gp[(int64_t)bk * n * n + idx];
+    gp[idx] = acc;
+}
+
+void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
+{
+    hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 255) / 256, b.nwin), dim3(256), 0, s, b);
 }
 
 template <int NB>

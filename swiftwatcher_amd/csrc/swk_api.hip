@@ -246,6 +246,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (ngroups > kMaxGroups) ngroups = kMaxGroups;
     if (ngroups > nwin) ngroups = nwin;
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
+    b.nred = b.nblk > 16 ? 1 : b.nblk;      // many slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 15) & ~(int64_t)15;
     b.fpad = (n + 15) & ~15;
     ctx->pstride = b.pstride;
@@ -313,7 +314,9 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
-        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]); launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
+        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]);
+          if (grp[g].b.nblk > 16) launch_gram_reduce(ctx->gstream[g], grp[g].b);
+          launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], ctx->gstream[g]));
     }
     for (int k = 1; k <= maxiter + 2; ++k) {
@@ -335,7 +338,9 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
             hipStream_t gs = ctx->gstream[g];
             HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
-            { Timed t(ctx, SWK_K_IALM_SMALL, gs); launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
+            { Timed t(ctx, SWK_K_IALM_SMALL, gs);
+              if (gr.b.nblk > 16) launch_gram_reduce(gs, gr.b);
+              launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
             HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
             if (k >= check_from) {
                 HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));

@@ -34,6 +34,7 @@ struct IalmBuffers {
     IalmWin *win;                  // [nwin]
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;
+    int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
     int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows
 };
@@ -44,6 +45,8 @@ void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant);
 // method: 0 = Newton-Schulz on the f64 matrix cores (Jacobi only as fallback), 1 = cyclic Jacobi
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);
+// sums the nblk Gram partial slabs of every live window into slab 0, in fixed order, chip-wide
+void launch_gram_reduce(hipStream_t s, const IalmBuffers &b);
 void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad);
 void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S);
 int  ialm_pass_nblk(int variant, int n, int P, int nwin);
