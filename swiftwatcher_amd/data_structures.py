@@ -91,40 +91,40 @@ class FrameQueue(deque):
         self.last_iters = None
         self._staging = None
 
-    # ---- container behaviour, :126-169 ----
+    # ---- container behaviour (reference :126-169): newest frame at index 0, oldest popped first ----
     def is_empty(self):
-        return len(self) == 0
+        return not len(self)
 
     def push_frame(self, input_frame, frame_number, timestamp):
-        super(FrameQueue, self).appendleft(Frame(input_frame, frame_number, timestamp))
+        self.appendleft(Frame(input_frame, frame_number, timestamp))
         self.frames_read += 1
 
     def push_list_of_frames(self, frame_list, frame_number_list, timestamp_list):
-        for frame, frame_number, timestamp in zip(frame_list, frame_number_list, timestamp_list):
-            self.push_frame(frame, frame_number, timestamp)
+        for triple in zip(frame_list, frame_number_list, timestamp_list):
+            self.push_frame(*triple)
 
     def pop_frame(self):
-        popped = super(FrameQueue, self).pop()
-        if popped.null is False:
-            self.frames_processed += 1
-        return popped
+        oldest = self.pop()
+        self.frames_processed += 0 if oldest.null else 1          # padding frames are not counted (:146-147)
+        return oldest
 
     def store_processed_queue(self, processed_frame_list, process_name):
-        for pos, frame in enumerate(processed_frame_list):
-            self[pos].processed_frames[process_name] = frame
+        for slot, image in zip(self, processed_frame_list):
+            slot.processed_frames[process_name] = image
 
     def store_segmented_queue(self, regionprops_lists, segment_image_list):
-        for pos, (rps, seg_images) in enumerate(zip(regionprops_lists, segment_image_list)):
-            self[pos].set_segments(rps, seg_images)
+        for slot, props, crops in zip(self, regionprops_lists, segment_image_list):
+            slot.set_segments(props, crops)
 
     def get_queue(self):
-        return [f.frame for f in self]
+        return [slot.frame for slot in self]
 
     def get_processed_queue(self, process_name):
-        return [f.processed_frames[process_name] for f in self]
+        return [slot.processed_frames[process_name] for slot in self]
 
     def get_last_processed_queue(self):
-        return [f.processed_frames[next(reversed(f.processed_frames))] for f in self]
+        latest = lambda stages: stages[next(reversed(stages))]      # noqa: E731  last stage stored
+        return [latest(slot.processed_frames) for slot in self]
 
     # ---- the hot path, :171-217 ----
     def preprocess_queue(self, crop_region, resize_dim=None):
