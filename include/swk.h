@@ -169,6 +169,18 @@ int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, i
 int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, int32_t H, int32_t W,
                            int32_t seg_cap, swk_segment *segs, int32_t *nseg);
 
+/* ---- classifier input (segment_classification.py:18-24) -------------------------------------------------
+ * ToPILImage -> Resize((24,24)) (Pillow's antialiased bilinear resampling, 8-bit fixed point, restated
+ * exactly) -> Pad(100) -> ToTensor -> Normalize(mean, std) for nseg segment crops.
+ *   crops    packed uint8 H x W x 3 images (host), crop i at byte offsets[i] with hw[2i] rows, hw[2i+1] columns
+ *            (each side 1..512)
+ *   patches  optional uint8 [nseg][24][24][3] (host): the resized crops
+ *   net      optional float32 [nseg][3][224][224]; net_mem says whether it is a host or a device pointer
+ *            (a torch tensor's data_ptr() feeds the network without another copy) */
+int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
+                             const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
+                             uint8_t *patches, float *net, int32_t net_mem);
+
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size
  * n_prev + n_curr, row-major.  Centroids are (row, col) float64 pairs; prev_hist0 = centroid of the first

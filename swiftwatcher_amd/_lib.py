@@ -79,6 +79,7 @@ _SIGS = {
     "swk_grey_open3x3_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
@@ -295,6 +296,28 @@ class Context:
         self._check(self._lib.swk_ccl_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], connectivity,
                                          label_order, _ptr(lab), _ptr(nc)))
         return (int(nc[0]), lab[0]) if single else (nc, lab)
+
+    def classifier_input(self, crops, mean, std, want_patches=False, net_ptr=None):
+        """swk_classifier_input for a list of HxWx3 uint8 crops.  Returns (patches or None, net or None):
+        net is a float32 host array (n, 3, 224, 224) unless net_ptr (a device pointer with room for it) is given."""
+        n = len(crops)
+        flat = [np.ascontiguousarray(c, np.uint8).reshape(-1) for c in crops]
+        sizes = np.array([f.size for f in flat], np.int64)
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        packed = np.concatenate(flat) if n else np.zeros(0, np.uint8)
+        hw = np.array([[c.shape[0], c.shape[1]] for c in crops], np.int32)
+        m = np.asarray(mean, np.float32)
+        s = np.asarray(std, np.float32)
+        patches = np.empty((n, 24, 24, 3), np.uint8) if want_patches else None
+        net = None
+        if net_ptr is None:
+            net = np.empty((n, 3, 224, 224), np.float32)
+            nptr, nmem = _ptr(net), MEM_HOST
+        else:
+            nptr, nmem = ctypes.c_void_p(net_ptr), MEM_DEVICE
+        self._check(self._lib.swk_classifier_input(self._h, _ptr(packed), packed.size, _ptr(offsets), _ptr(hw), n,
+                                                   _ptr(m), _ptr(s), _ptr(patches), nptr, nmem))
+        return patches, net
 
     def regionprops_u8(self, labels, seg_cap=255):
         s, single = self._planes(labels)

@@ -18,7 +18,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -767,6 +767,35 @@ int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, i
     launch_regionprops(ctx->stream, din, count, H, W, cb, seg_cap, dsegs, dnseg);
     HIPCHK(ctx, hipMemcpyAsync(segs, dsegs, (size_t)count * seg_cap * sizeof(swk_segment), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(nseg, dnseg, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
+                             const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
+                             uint8_t *patches, float *net, int32_t net_mem)
+{
+    if (!ctx || !crops || !offsets || !hw || !mean || !std_ || nseg < 1 || crops_bytes < 1 || (!patches && !net))
+        return fail(ctx, SWK_ERR_ARG, "bad argument");
+    for (int i = 0; i < nseg; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h < 1 || w < 1 || h > 512 || w > 512) return fail(ctx, SWK_ERR_ARG, "segment crops must be 1..512 pixels on each side");
+        if (offsets[i] < 0 || offsets[i] + (int64_t)h * w * 3 > crops_bytes) return fail(ctx, SWK_ERR_ARG, "crop outside the packed buffer");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    uint8_t *dcrops, *dpatch = nullptr; int64_t *doffs; int32_t *dhw; float *dnet = nullptr;
+    NEED(ctx, SL_CL_CROPS, (size_t)crops_bytes, dcrops);
+    NEED(ctx, SL_CL_OFFS, (size_t)nseg * 8, doffs);
+    NEED(ctx, SL_CL_HW, (size_t)nseg * 8, dhw);
+    HIPCHK(ctx, hipMemcpyAsync(dcrops, crops, (size_t)crops_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(doffs, offsets, (size_t)nseg * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dhw, hw, (size_t)nseg * 8, hipMemcpyHostToDevice, s));
+    if (patches) NEED(ctx, SL_CL_PATCH, (size_t)nseg * 24 * 24 * 3, dpatch);
+    const size_t net_bytes = (size_t)nseg * 3 * 224 * 224 * sizeof(float);
+    if (net) { if (net_mem == SWK_MEM_DEVICE) dnet = net; else NEED(ctx, SL_CL_NET, net_bytes, dnet); }
+    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, mean, std_);
+    if (patches) HIPCHK(ctx, hipMemcpyAsync(patches, dpatch, (size_t)nseg * 24 * 24 * 3, hipMemcpyDeviceToHost, s));
+    if (net && net_mem != SWK_MEM_DEVICE) HIPCHK(ctx, hipMemcpyAsync(net, dnet, net_bytes, hipMemcpyDeviceToHost, s));
     return sync(ctx);
 }
 

@@ -68,6 +68,10 @@ void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
                          int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out);
 
+// classify_input.hip
+void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
+                             uint8_t *patches, float *net, const float *mean, const float *sd);
+
 // ccl.hip
 struct CclBuffers {
     int32_t *parent;               // [F][Pp] in the id space chosen by label_order

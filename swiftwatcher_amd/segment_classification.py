@@ -102,7 +102,17 @@ class SegmentClassifier:
         self._border = ((0.0 - mean) / std).expand(1, 3, 224, 224).contiguous()
 
     def preprocess(self, segment_images):
-        """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device."""
+        """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device.
+        On the GPU the whole chain (Pillow-exact resize, pad, /255, normalise) is one HIP kernel that writes the
+        network's input tensor in place (swk_classifier_input); crops larger than 512 px or a CPU device use the
+        torch / Pillow statements below."""
+        if self.device.type == "cuda" and all(max(im.shape[0], im.shape[1]) <= 512 for im in segment_images):
+            from . import _lib
+            x = torch.empty((len(segment_images), 3, 224, 224), dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
+            _lib.default_context(self.device.index or 0).classifier_input(segment_images, IMAGENET_MEAN, IMAGENET_STD,
+                                                                          net_ptr=x.data_ptr())
+            return x
         patches = np.stack([resize_segment(im) for im in segment_images])              # (B, 24, 24, 3) u8
         t = torch.from_numpy(patches).to(self.device).permute(0, 3, 1, 2).to(torch.float32).div_(255.0)   # ToTensor
         t = (t - self._mean) / self._std                                               # Normalize

@@ -86,3 +86,35 @@ def test_gpu_scores_and_decisions_match_oracle(tmp_path):
         if m:
             assert (id(s) in kept_ids) == bool(k)
     assert 0 < exp_keep.sum() < len(segs)
+
+
+@pytest.mark.gpu
+def test_hip_classifier_input_is_pillow_exact(tmp_path):
+    """swk_classifier_input (resize + pad + ToTensor + Normalize in one HIP kernel) against Pillow / the torchvision
+    statements restated in the oracle: uint8 patches bit-exact, float32 network input bit-exact."""
+    from PIL import Image
+    from swiftwatcher_amd import _lib
+    from oracle import classifier_ref as ref
+    rng = np.random.default_rng(5)
+    shapes = [(24, 24), (24, 31), (40, 24), (25, 25), (37, 61), (90, 130), (212, 424), (24, 25), (47, 48), (512, 300), (1, 1), (3, 500)]
+    crops = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]
+    crops.append(np.zeros((30, 30, 3), np.uint8))
+    crops.append(np.full((60, 33, 3), 255, np.uint8))
+    ctx = _lib.Context(0)
+    patches, net = ctx.classifier_input(crops, ref.MEAN, ref.STD, want_patches=True)
+    bil = getattr(Image, "Resampling", Image).BILINEAR
+    for i, c in enumerate(crops):
+        exp = np.asarray(Image.fromarray(c).resize((24, 24), bil))
+        np.testing.assert_array_equal(patches[i], exp, err_msg="crop %d %r" % (i, c.shape))
+        np.testing.assert_array_equal(net[i], ref.transform(c)[0].numpy(), err_msg="net input %d" % i)
+    with pytest.raises(_lib.SwkError):
+        ctx.classifier_input([np.zeros((513, 10, 3), np.uint8)], ref.MEAN, ref.STD)
+    ctx.close()
+    # the classifier's own preprocess() takes that path on the GPU and must agree with the host statements
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    path = tmp_path / "w.pt"
+    torch.save(ref.random_state_dict(4), path)
+    clf = SegmentClassifier(str(path))
+    x = clf.preprocess(crops[:9]).cpu()
+    for i in range(9):
+        assert torch.equal(x[i], ref.transform(crops[i])[0])

@@ -1,6 +1,7 @@
 """Throughput of the segment classifier on the MI355X: batched SqueezeNet-1.0 forward
 through PyTorch-ROCm (MIOpen), fp32, eval mode.  1.465 GFLOP per segment (0.7326 GMAC).  Random weights of the
-right shapes (tests use the same generator); preprocessing (PIL resize on the host) is timed separately."""
+right shapes (tests use the same generator); preprocessing (the HIP resize/pad/normalise kernel, fed from host
+crops) is timed separately."""
 import json
 import os
 import sys
@@ -45,7 +46,7 @@ def main():
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         out["batch_%d" % bs] = {"segments_per_s": round(bs / dt, 1), "tflops": round(bs * GFLOP_PER_SEGMENT / dt / 1e3, 2)}
-    out["host_preprocess_segments_per_s"] = round(2048 / t_pre, 1)
+    out["preprocess_segments_per_s"] = round(2048 / t_pre, 1)      # swk_classifier_input incl. host packing + H2D
     out["dtype"] = "f32"
     out["peak_f32_matrix_tflops"] = 157.3
     print(json.dumps(out))
