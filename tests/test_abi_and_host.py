@@ -119,3 +119,16 @@ def test_framequeue_bookkeeping():
     q.pop_frame(); q.pop_frame()
     assert q.frames_processed == 3 and q.is_empty()               # null frames are not counted
     assert Frame().null
+
+
+def test_array_reader_mirrors_framereader_bookkeeping():
+    from swiftwatcher_amd.io_frames import ArrayReader
+    frames = [np.full((4, 5, 3), i, np.uint8) for i in range(5)]
+    r = ArrayReader(frames, fps=10.0)
+    assert (r.start_frame, r.end_frame, r.total_frames) == (0, 5, 5)
+    got, nums, stamps = r.get_n_frames(8)
+    assert nums == [0, 1, 2, 3, 4, 5, -1, -1]            # frame "5" is inside the inclusive range test ...
+    assert int(got[5][0, 0, 0]) == 4 and r.read_errors == 1   # ... and is served by the last good frame
+    assert not got[6].any() and got[6].shape == (4, 5, 3) and stamps[6] == "00:00:00.000"
+    assert (stamps[3] - stamps[0]).total_seconds() == pytest.approx(0.3)
+    assert r.frames_read == 5

@@ -398,18 +398,22 @@ def test_swift_count_on_a_clip_matches_cpu_pipeline(orc):
     roi_mask = np.zeros((96, 160), np.uint8)
     roi_mask[40:, :] = 255
     count, events = pipeline.count_swifts(list(clip), crop_region, roi_mask)
-    # CPU side: oracle windows -> identical bookkeeping
+    # CPU side: the same reader bookkeeping (null padding, duplicated last frame), oracle windows, same tracker
+    from swiftwatcher_amd.io_frames import ArrayReader
+    reader = ArrayReader(list(clip))
     tracker = SegmentTracker(roi_mask)
-    for w0 in range(0, total, 21):
-        idx = list(range(w0, min(w0 + 21, total)))
-        stack = [clip[i][20:116, 30:190] for i in idx] + [np.zeros((96, 160, 3), np.uint8)] * (21 - len(idx))
-        ref = orc.window(np.ascontiguousarray(np.stack(stack[::-1])))
-        for pos in range(20, -1, -1):                       # oldest first
-            t = w0 + 20 - pos
-            fr = Frame(None, t if t < total else -1, "%010.3f" % (t / 30.0))
+    processed = 0
+    while processed < reader.total_frames:
+        frames, numbers, stamps = reader.get_n_frames(21)
+        roi = np.stack([f[20:116, 30:190] for f in frames][::-1])       # queue order: newest first
+        ref = orc.window(np.ascontiguousarray(roi))
+        for pos in range(20, -1, -1):                                     # pop order: oldest first
+            k = 20 - pos
+            fr = Frame(None, numbers[k], stamps[k])
             fr.segments = [Segment(RegionProps(s["label"], s["bbox"], s["centroid"], s["area"]), fr.frame_number, fr.timestamp, None)
                            for s in ref["segments"][pos]]
             tracker.step(fr)
+            processed += 0 if fr.null else 1
     assert [(e[-1].parent_frame_number, len(e)) for e in events] == [(e[-1].parent_frame_number, len(e)) for e in tracker.detected_events]
     assert count == ec.count_swifts(tracker.detected_events)
     assert len(events) >= 1
