@@ -548,10 +548,19 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         NEED(ctx, SL_ROI, plane * in->channels, roi);
         Timed t(ctx, SWK_K_COPY);
         const size_t rowb = (size_t)W * in->channels;
-        for (int f = 0; f < F; ++f)
-            HIPCHK(ctx, hipMemcpy2DAsync(roi + (size_t)f * P * in->channels, rowb,
-                                         in->frames + (int64_t)f * fs + (int64_t)y0 * rs + (int64_t)x0 * in->channels, (size_t)rs,
-                                         rowb, H, hipMemcpyHostToDevice, s));
+        if (x0 == 0 && (size_t)rs == rowb && fs == (int64_t)H * rs) {
+            // pre-cropped, densely packed ROI frames: one copy for the whole batch
+            HIPCHK(ctx, hipMemcpyAsync(roi, in->frames + (int64_t)y0 * rs, plane * in->channels, hipMemcpyHostToDevice, s));
+        } else if (x0 == 0 && (size_t)rs == rowb) {
+            for (int f = 0; f < F; ++f)                    // full-width rows: one contiguous block per frame
+                HIPCHK(ctx, hipMemcpyAsync(roi + (size_t)f * P * in->channels, in->frames + (int64_t)f * fs + (int64_t)y0 * rs,
+                                           (size_t)P * in->channels, hipMemcpyHostToDevice, s));
+        } else {
+            for (int f = 0; f < F; ++f)
+                HIPCHK(ctx, hipMemcpy2DAsync(roi + (size_t)f * P * in->channels, rowb,
+                                             in->frames + (int64_t)f * fs + (int64_t)y0 * rs + (int64_t)x0 * in->channels, (size_t)rs,
+                                             rowb, H, hipMemcpyHostToDevice, s));
+        }
         dframes = roi; fs = (int64_t)P * in->channels; rs = (int64_t)rowb; x0 = 0; y0 = 0;
     }
     // ---- stage buffers (caller's device buffers are written in place) ----

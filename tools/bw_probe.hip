@@ -9,7 +9,7 @@
 #include <vector>
 
 template <int MODE>
-__global__ __launch_bounds__(256) void probe(double *__restrict__ A, double *__restrict__ Y, int n, int P, int tiles_per_wave)
+__global__ __launch_bounds__(256) void probe(double *__restrict__ A, double *__restrict__ Y, int n, int P, int tiles_per_wave, double *__restrict__ A2 = nullptr, double *__restrict__ Y2 = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * 4;
@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void probe(double *__restrict__ A, double *__r
             double a[16], y[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) { a[t] = A[o + (size_t)4 * t * P]; y[t] = Y[o + (size_t)4 * t * P]; }
+            double *Ao = A2 ? A2 : A, *Yo = Y2 ? Y2 : Y;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { A[o + (size_t)4 * t * P] = a[t] + y[t]; Y[o + (size_t)4 * t * P] = a[t] - y[t]; }
+            for (int t = 0; t < 16; ++t) { Ao[o + (size_t)4 * t * P] = a[t] + y[t]; Yo[o + (size_t)4 * t * P] = a[t] - y[t]; }
         }
     } else if (MODE == 1) {
         const int ntiles = P / 32;
@@ -54,6 +55,23 @@ int main()
     hipMalloc(&A, elems * 8); hipMalloc(&Y, elems * 8);
     hipMemset(A, 0, elems * 8); hipMemset(Y, 0, elems * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double *A2, *Y2;
+    hipMalloc(&A2, elems * 8); hipMalloc(&Y2, elems * 8);
+    for (int blocks : {4096, 16384}) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 6; ++rep) {
+            hipEventRecord(e0);
+            for (int w = 0; w < W; ++w) {
+                size_t off = (size_t)w * n * P;
+                if (rep & 1) probe<0><<<blocks / W, 256>>>(A2 + off, Y2 + off, n, P, 0, A + off, Y + off);
+                else probe<0><<<blocks / W, 256>>>(A + off, Y + off, n, P, 0, A2 + off, Y2 + off);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("mode 0 OUT-OF-PLACE blocks %5d: %.3f ms  %.0f GB/s\n", blocks, best, elems * 32.0 / best / 1e6);
+    }
     for (int mode = 0; mode < 3; ++mode)
         for (int blocks : {4096, 8192, 16384, 32768}) {
             float best = 1e9f;
