@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     }
 }
 
-constexpr int kRunCap = 2048;          // runs per frame handled in LDS
+constexpr int kRunCap = 1024;          // runs per frame handled in LDS (a sparse frame has a few hundred)
 size_t ccl_frame_lds_bytes(int H, int W)
 {
     const size_t P = (size_t)H * W;

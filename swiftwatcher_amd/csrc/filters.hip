@@ -104,6 +104,8 @@ __device__ __forceinline__ int reflect101(int p, int len)
 __device__ __forceinline__ int clampi(int p, int len) { return p < 0 ? 0 : (p >= len ? len - 1 : p); }
 
 constexpr int kMaxTaps = 81;   // radius <= 4 (d <= 9)
+constexpr int kTH = 32, kTW = 64;        // output tile of the tiled kernels
+constexpr int kHalo = 5;                 // fused kernel: bilateral radius 3 + erosion 1 + dilation 1
 
 // Generic bilateral (any radius <= 4), one thread per pixel, global reads (L1/L2 absorb the reuse).
 // Stage-level entry point; the hot path uses the fused tile kernel below.
@@ -164,7 +166,6 @@ void launch_thresh(hipStream_t s, const uint8_t *src, int64_t count, int thresh,
 
 // 3x3 grey opening = min3x3 then max3x3; scipy's 'reflect' border equals clamp-to-edge at radius 1.
 // Tile 32x64 outputs; erosion is needed on a 1-px ring, the source on a 2-px ring.
-constexpr int kTH = 32, kTW = 64;
 
 __global__ __launch_bounds__(256) void k_open3x3(const uint8_t *__restrict__ src, int H, int W, uint8_t *__restrict__ dst)
 {
@@ -218,148 +219,217 @@ void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint
 }
 
 // ---------------------------------------------------------------------------------
-// Fused hot-path kernel: bilateral (radius 3, 29 taps) -> to-zero threshold -> 3x3 opening.
-// One 32x64 output tile per workgroup.  Rings: opening needs the thresholded image on a 2-px
-// ring, the bilateral filter needs the sparse image 3 px beyond that: a (32+10)x(64+10) source
-// tile in LDS, read once from HBM.  The sparse image is mostly zero: a pixel whose whole
-// neighbourhood is zero is zero after the filter (sum = 0), so an all-zero source tile skips
-// the arithmetic altogether.
+// Tile occupancy of the sparse image: flags[f][tile] = 1 when the tile's source window (tile + 5-px halo)
+// holds a nonzero pixel.  One dword (4 pixels) per thread; flags are plain byte stores of 1 (every writer
+// writes the same value).  About half of the 32x64 tiles of a frame are empty: the fused kernel returns
+// at once for those and their outputs stay at the zero the buffers were cleared to.
+// ---------------------------------------------------------------------------------
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_tile_flags(const uint8_t *__restrict__ src, int H, int W, int ntx, int nty,
+                                                    uint8_t *__restrict__ flags)
+{
+    const int f = blockIdx.y;
+    const int P = H * W;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P / VEC) return;
+    const uint8_t *img = src + (int64_t)f * P;
+    uint32_t v;
+    if (VEC == 4) v = ((const uint32_t *)img)[i];
+    else v = img[i];
+    if (!v) return;
+    const int p = i * VEC;
+    const int r = p / W, c = p - r * W;          // a 4-pixel word may wrap to the next row: widen the column range
+    int c_lo = c, c_hi = c + VEC - 1, r_hi = r;
+    if (c_hi >= W) { c_lo = 0; c_hi = W - 1; r_hi = r + 1 < H ? r + 1 : H - 1; }
+    const int tr0 = (r - kHalo > 0 ? r - kHalo : 0) / kTH, tr1 = (r_hi + kHalo < H - 1 ? r_hi + kHalo : H - 1) / kTH;
+    const int tc0 = (c_lo - kHalo > 0 ? c_lo - kHalo : 0) / kTW, tc1 = (c_hi + kHalo < W - 1 ? c_hi + kHalo : W - 1) / kTW;
+    uint8_t *fl = flags + (int64_t)f * ntx * nty;
+    for (int tr = tr0; tr <= tr1; ++tr)
+        for (int tc = tc0; tc <= tc1; ++tc) fl[tr * ntx + tc] = 1;
+}
+
+// ---------------------------------------------------------------------------------
+// Fused hot-path kernel: bilateral (radius 3, 29 taps) -> to-zero threshold -> 3x3 opening, one 32x64 output
+// tile per workgroup.  Opening needs the thresholded image on a 2-px ring, the bilateral filter the sparse image
+// 3 px beyond that: a 42-row source tile in LDS (80 columns: the window starts 8 px left of the tile so interior
+// tiles load it as aligned dwords).  The stage is instruction-bound, so the work is made as sparse as the data:
+//   * empty tiles never start (tile flags), outputs are pre-cleared;
+//   * a separable 7x7 OR finds the ring cells whose neighbourhood holds any nonzero pixel; only those are
+//     compacted into a list and run the 29-tap loop (a cell with an all-zero neighbourhood filters to 0);
+//   * erosion of a zero pixel is zero without looking further; an all-zero eroded tile ends the block.
 // ---------------------------------------------------------------------------------
 constexpr int kR = 3;                    // bilateral radius of the fused kernel
-constexpr int kSH = kTH + 4 + 2 * kR;    // 42
-constexpr int kSW = kTW + 4 + 2 * kR;    // 74
-constexpr int kBH = kTH + 4, kBW = kTW + 4;
+constexpr int kSH = kTH + 2 * kHalo;     // 42 source rows
+constexpr int kSP = 80;                  // source pitch: image columns c0-8 .. c0+71
+constexpr int kSX = 8;                   // column of the source window = image column - c0 + kSX
+constexpr int kBH = kTH + 4, kBW = kTW + 4;      // thresholded ring 36 x 68
+constexpr int kEH = kTH + 2, kEW = kTW + 2;      // eroded ring 34 x 66
 
 __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict__ src, int H, int W,
                                                       const float *__restrict__ color_w, const float *__restrict__ space_w,
                                                       const int8_t *__restrict__ tdr, const int8_t *__restrict__ tdc,
                                                       int maxk, int use_fma, int thresh,
                                                       uint8_t *__restrict__ bil_out, uint8_t *__restrict__ thr_out,
-                                                      uint8_t *__restrict__ open_out)
+                                                      uint8_t *__restrict__ open_out, const uint8_t *__restrict__ flags)
 {
-    __shared__ uint8_t s_src[kSH * kSW];
+    // empty tile (source window all zero): every stage outputs zero, which the buffers already hold
+    if (flags && !flags[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[kSH * kSP];
+    __shared__ uint8_t s_or[kSH * kBW];            // horizontal 7-wide OR of the source, per ring column
     __shared__ uint8_t s_thr[kBH * kBW];
-    __shared__ uint8_t s_er[(kTH + 2) * (kTW + 2)];
+    __shared__ uint8_t s_er[kEH * kEW];
+    __shared__ uint16_t s_list[kBH * kBW];
     __shared__ float s_cw[256];
     __shared__ float s_sw[32];
     __shared__ int s_ofs[32];
-    __shared__ int s_any;
-    __shared__ int s_row_any[kSH], s_col_any[kSW];
-    const int f = blockIdx.z;
+    __shared__ int s_count, s_er_any;
+    const int f = blockIdx.z, tid = threadIdx.x;
     const int r0 = blockIdx.y * kTH, c0 = blockIdx.x * kTW;
     const uint8_t *img = src + (int64_t)f * H * W;
-    if (threadIdx.x == 0) s_any = 0;
-    if (threadIdx.x < kSH) s_row_any[threadIdx.x] = 0;
-    if (threadIdx.x < kSW) s_col_any[threadIdx.x] = 0;
-    __syncthreads();
-    int any = 0;
-    for (int i = threadIdx.x; i < kSH * kSW; i += blockDim.x) {
-        const int lr = i / kSW, lc = i % kSW;
-        // Cell (lr, lc) stands for image coordinate (r0+lr-5, c0+lc-5).  Taps of in-image pixels
-        // reach outside the image by up to kR and use BORDER_REFLECT_101 there, so every cell
-        // holds img[reflect101(coordinate)]; cells far outside the image are never consumed.
-        const int r = reflect101(r0 + lr - 2 - kR, H);
-        const int c = reflect101(c0 + lc - 2 - kR, W);
-        const uint8_t v = img[r * W + c];
-        s_src[i] = v;
-        any |= v;
-        if (v) { s_row_any[lr] = 1; s_col_any[lc] = 1; }
+    if (tid == 0) { s_count = 0; s_er_any = 0; }
+    for (int i = tid; i < 256; i += 256) s_cw[i] = color_w[i];
+    if (tid < maxk) {
+        s_sw[tid] = space_w[tid];
+        s_ofs[tid] = (int)tdr[tid] * kSP + (int)tdc[tid];
     }
-    if (any) s_any = 1;
-    __syncthreads();
-    const bool nonzero = s_any != 0;
-    if (!nonzero) {
-        // the sparse image is zero over the whole tile and its halo: every stage outputs zero
-        for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
-            const int r = r0 + i / kTW, c = c0 + i % kTW;
-            if (r < H && c < W) {
-                const int64_t o = ((int64_t)f * H + r) * W + c;
-                if (bil_out) bil_out[o] = 0;
-                if (thr_out) thr_out[o] = 0;
-                open_out[o] = 0;
-            }
+    for (int i = tid; i < kBH * kBW; i += 256) s_thr[i] = 0;
+    // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71 ----
+    const bool interior = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W &&
+                          (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
+    if (interior) {
+        for (int i = tid; i < kSH * (kSP / 4); i += 256) {
+            const int sr = i / (kSP / 4), q = i - sr * (kSP / 4);
+            ((uint32_t *)s_src)[i] = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
         }
-        return;
-    }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cw[i] = color_w[i];
-    if (threadIdx.x < maxk) {
-        s_sw[threadIdx.x] = space_w[threadIdx.x];
-        s_ofs[threadIdx.x] = (int)tdr[threadIdx.x] * kSW + (int)tdc[threadIdx.x];
+    } else {
+        for (int i = tid; i < kSH * kSP; i += 256) {
+            const int sr = i / kSP, sc = i - sr * kSP;
+            // taps of in-image pixels reach outside the image by up to kR and use BORDER_REFLECT_101 there, so every
+            // cell holds img[reflect101(coordinate)]; cells far outside the image are never consumed
+            s_src[i] = img[reflect101(r0 - kHalo + sr, H) * W + reflect101(c0 - kSX + sc, W)];
+        }
     }
     __syncthreads();
-    // bilateral + threshold on the (32+4)x(64+4) ring, in-image cells only
-    for (int i = threadIdx.x; i < kBH * kBW; i += blockDim.x) {
-        const int lr = i / kBW, lc = i % kBW;
-        const int r = r0 + lr - 2, c = c0 + lc - 2;
-        uint8_t outv = 0;
-        // a pixel whose 7x7 neighbourhood holds no nonzero source pixel filters to 0: skip it when the
-        // source rows lr..lr+6 or columns lc..lc+6 of the tile are all empty
+    // ---- horizontal OR over the 7 source columns under each ring column ----
+    for (int i = tid; i < kSH * kBW; i += 256) {
+        const int sr = i / kBW, lc = i - sr * kBW;
+        const uint8_t *p = &s_src[sr * kSP + lc + (kSX - kHalo)];       // ring column lc = source columns lc+3 .. lc+9
+        s_or[i] = p[0] | p[1] | p[2] | p[3] | p[4] | p[5] | p[6];
+    }
+    __syncthreads();
+    // ---- live ring cells: in the image and with a nonzero pixel somewhere in their 7x7 neighbourhood ----
+    for (int base = 0; base < kBH * kBW; base += 256) {
+        const int i = base + tid;
         bool live = false;
-        if (r >= 0 && r < H && c >= 0 && c < W) {
-            int ra = 0, ca = 0;
-#pragma unroll
-            for (int k = 0; k <= 2 * kR; ++k) { ra |= s_row_any[lr + k]; ca |= s_col_any[lc + k]; }
-            live = ra && ca;
-        }
-        if (live) {
-            const int ctr = (lr + kR) * kSW + (lc + kR);
-            const int v0 = s_src[ctr];
-            float sum = 0.f, wsum = 0.f;
-            for (int k = 0; k < maxk; ++k) {
-                const int v = s_src[ctr + s_ofs[k]];
-                const int dv = v - v0;
-                const float w = s_sw[k] * s_cw[dv < 0 ? -dv : dv];
-                if (use_fma) sum = __fmaf_rn((float)v, w, sum);
-                else sum = sum + (float)v * w;
-                wsum = wsum + w;
+        if (i < kBH * kBW) {
+            const int lr = i / kBW, lc = i - lr * kBW;
+            const int r = r0 - 2 + lr, c = c0 - 2 + lc;
+            if (r >= 0 && r < H && c >= 0 && c < W) {
+                const uint8_t *p = &s_or[lr * kBW + lc];
+                live = (p[0] | p[kBW] | p[2 * kBW] | p[3 * kBW] | p[4 * kBW] | p[5 * kBW] | p[6 * kBW]) != 0;
             }
-            outv = (uint8_t)__float2int_rn(sum / wsum);
         }
-        const bool interior = lr >= 2 && lr < kBH - 2 && lc >= 2 && lc < kBW - 2 && r < H && c < W;
-        if (interior && bil_out) bil_out[((int64_t)f * H + r) * W + c] = outv;
+        const unsigned long long m = __ballot(live);
+        int wbase = 0;
+        if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_count, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (live) s_list[wbase + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // ---- bilateral + threshold on the compacted list ----
+    const int nlive = s_count;
+    for (int j = tid; j < nlive; j += 256) {
+        const int i = s_list[j];
+        const int lr = i / kBW, lc = i - lr * kBW;
+        const int ctr = (lr + kR) * kSP + lc + (kSX - 2);             // ring (lr, lc) = source (lr+3, lc+6)
+        const int v0 = s_src[ctr];
+        float sum = 0.f, wsum = 0.f;
+        for (int k = 0; k < maxk; ++k) {
+            const int v = s_src[ctr + s_ofs[k]];
+            const int dv = v - v0;
+            const float w = s_sw[k] * s_cw[dv < 0 ? -dv : dv];
+            if (use_fma) sum = __fmaf_rn((float)v, w, sum);
+            else sum = sum + (float)v * w;
+            wsum = wsum + w;
+        }
+        uint8_t outv = (uint8_t)__float2int_rn(sum / wsum);             // cvRound: half to even
+        const int r = r0 - 2 + lr, c = c0 - 2 + lc;
+        const bool inner = lr >= 2 && lr < kBH - 2 && lc >= 2 && lc < kBW - 2;
+        if (inner && bil_out && outv) bil_out[((int64_t)f * H + r) * W + c] = outv;
         outv = outv > thresh ? outv : (uint8_t)0;
-        if (interior && thr_out) thr_out[((int64_t)f * H + r) * W + c] = outv;
+        if (inner && thr_out && outv) thr_out[((int64_t)f * H + r) * W + c] = outv;
         s_thr[i] = outv;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (kTH + 2) * (kTW + 2); i += blockDim.x) {
-        const int lr = i / (kTW + 2), lc = i % (kTW + 2);
-        const int r = clampi(r0 + lr - 1, H), c = clampi(c0 + lc - 1, W);
-        int acc = 255;
-        for (int dr = -1; dr <= 1; ++dr)
-            for (int dc = -1; dc <= 1; ++dc) {
-                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
-                const int v = s_thr[(rr - r0 + 2) * kBW + (cc - c0 + 2)];
-                acc = v < acc ? v : acc;
-            }
+    // ---- erosion (window coordinates clamp to the IMAGE: scipy 'reflect' == edge replicate at radius 1) ----
+    int er_any = 0;
+    for (int i = tid; i < kEH * kEW; i += 256) {
+        const int er = i / kEW, ec = i - er * kEW;
+        const int r = clampi(r0 - 1 + er, H), c = clampi(c0 - 1 + ec, W);
+        int acc = s_thr[(r - r0 + 2) * kBW + (c - c0 + 2)];
+        if (acc) {                                   // min over the window is 0 as soon as the centre is 0
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int v = s_thr[(clampi(r + dr, H) - r0 + 2) * kBW + (clampi(c + dc, W) - c0 + 2)];
+                    acc = v < acc ? v : acc;
+                }
+        }
         s_er[i] = (uint8_t)acc;
+        er_any |= acc;
     }
+    if (er_any) s_er_any = 1;
     __syncthreads();
-    for (int i = threadIdx.x; i < kTH * kTW; i += blockDim.x) {
-        const int lr = i / kTW, lc = i % kTW;
+    if (!s_er_any) return;                           // opened tile is all zero: already the buffer's content
+    // ---- dilation ----
+    for (int i = tid; i < kTH * kTW; i += 256) {
+        const int lr = i / kTW, lc = i - lr * kTW;
         const int r = r0 + lr, c = c0 + lc;
         if (r >= H || c >= W) continue;
         int acc = 0;
         for (int dr = -1; dr <= 1; ++dr)
             for (int dc = -1; dc <= 1; ++dc) {
-                const int rr = clampi(r + dr, H), cc = clampi(c + dc, W);
-                const int v = s_er[(rr - r0 + 1) * (kTW + 2) + (cc - c0 + 1)];
+                const int v = s_er[(clampi(r + dr, H) - r0 + 1) * kEW + (clampi(c + dc, W) - c0 + 1)];
                 acc = v > acc ? v : acc;
             }
-        open_out[((int64_t)f * H + r) * W + c] = (uint8_t)acc;
+        if (acc) open_out[((int64_t)f * H + r) * W + c] = (uint8_t)acc;
     }
 }
 
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
-                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out)
+                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out, uint8_t *flags)
 {
+    const int ntx = (W + kTW - 1) / kTW, nty = (H + kTH - 1) / kTH;
+    const size_t plane = (size_t)F * H * W;
+    // the kernel stores nonzero results only: outputs start cleared
+    (void)hipMemsetAsync(open_out, 0, plane, s);
+    if (bil_out) (void)hipMemsetAsync(bil_out, 0, plane, s);
+    if (thr_out) (void)hipMemsetAsync(thr_out, 0, plane, s);
+    if (flags) {
+        // tile occupancy first, so that empty tiles need no work at all
+        (void)hipMemsetAsync(flags, 0, (size_t)F * ntx * nty, s);
+        const int P = H * W;
+        const bool vec4 = (P % 4 == 0) && (((uintptr_t)src & 3) == 0);
+        for (int f0 = 0; f0 < F; f0 += 32768) {
+            const int fc = F - f0 < 32768 ? F - f0 : 32768;
+            if (vec4)
+                hipLaunchKernelGGL(k_tile_flags<4>, dim3((P / 4 + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
+                                   flags + (size_t)f0 * ntx * nty);
+            else
+                hipLaunchKernelGGL(k_tile_flags<1>, dim3((P + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
+                                   flags + (size_t)f0 * ntx * nty);
+        }
+    }
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
         const int64_t o = (int64_t)f0 * H * W;
-        hipLaunchKernelGGL(k_filter_fused, dim3((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, fc), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_filter_fused, dim3(ntx, nty, fc), dim3(256), 0, s,
                            src + o, H, W, t.color_w, t.space_w, t.tap_dr, t.tap_dc, t.maxk, use_fma, thresh,
-                           bil_out ? bil_out + o : nullptr, thr_out ? thr_out + o : nullptr, open_out + o);
+                           bil_out ? bil_out + o : nullptr, thr_out ? thr_out + o : nullptr, open_out + o,
+                           flags ? flags + (size_t)f0 * ntx * nty : nullptr);
     }
 }
+
+size_t filter_flags_bytes(int F, int H, int W) { return (size_t)F * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH); }
 
 }  // namespace swk
