@@ -26,8 +26,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-BYTES_STEADY = 33              # per element per iteration: X u8 + A,Y f64 read, A,Y f64 written
-BYTES_FIRST = 17               # first iteration: previous state is implicit (no A/Y read)
+# algorithmic bytes per matrix element and IALM iteration of the streaming pass:
+#   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
+#   variant 3 (M state, the default):          X u8 + M f64 + U f32 read, M f64 + U f32 + S u8 written = 26; first = 14
+PASS_BYTES = {1: (33, 17), 2: (33, 17), 3: (26, 14)}
 
 
 def parse():
@@ -149,6 +151,8 @@ def main():
         pass_ms, pass_launches = prof["ialm_pass"]
         # exact algorithmic bytes streamed by the full passes of ONE step (same every step: same data)
         elems = n * P
+        variant = args.variant if args.variant else 3
+        BYTES_STEADY, BYTES_FIRST = PASS_BYTES[variant]
         step_bytes = int(sum(BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems
         total_bytes = step_bytes * args.steps
         achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
@@ -157,7 +161,7 @@ def main():
         if os.path.exists(pmc_file):
             try:       # PMC passes are separate rocprofv3 runs (tools/pmc_pass.sh); valid for the same n and ROI
                 pmc = json.load(open(pmc_file))
-                if pmc.get("n") == n and pmc.get("P") == P:
+                if pmc.get("n") == n and pmc.get("P") == P and pmc.get("variant", 2) == variant:
                     traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
             except Exception:
                 traffic = None
@@ -179,7 +183,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
-                         "bytes_per_launch": int(total_bytes / max(pass_launches, 1))},
+                         "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
+                         "bytes_per_element_iteration": BYTES_STEADY, "pass_variant": variant},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if isinstance(v, tuple)},
         }
         if args.host_input:

@@ -236,7 +236,7 @@ __global__ void k_rpca_epilogue(const double *__restrict__ E, int64_t count, uin
 int ialm_pass_nblk(int variant, int n, int P, int nwin)
 {
     (void)n;
-    if (variant == 2) {
+    if (variant >= 2) {
         // 256-thread blocks, two resident per CU (LDS and registers).
         // Several rounds of blocks per CU keep the tail short when a few CUs are busy with another
         // group's eigen-solve; the cap bounds the Gram partial slabs (nblk x n^2 doubles per window).
@@ -288,8 +288,11 @@ static void launch_v1(hipStream_t s, const IalmBuffers &b)
 void launch_ialm_pass_v2(hipStream_t s, const IalmBuffers &b, int mode);   // ialm_mfma.hip
 bool ialm_v2_supported(int n);
 
-void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant)
+void launch_ialm_pass_v3(hipStream_t s, const IalmBuffers &b, int mode, int k);
+
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k)
 {
+    if (variant == 3) { launch_ialm_pass_v3(s, b, mode, k); return; }
     if (variant == 2) { launch_ialm_pass_v2(s, b, mode); return; }
     const bool we = b.E != nullptr;
     if (mode == 0) launch_v1<0, false>(s, b);

@@ -18,7 +18,7 @@
 //   (G is symmetric); accumulators stay in registers over the wave's whole tile loop.
 //
 // No barrier inside the loop: waves only share the read-only B matrix.
-// Roofline: HBM.  33 B/element/iteration against 4n^2 flop/pixel -> 7.8 flop/B at n = 64, under the
+// Roofline: HBM.  v2: 33 B/element/iteration (+1 for the sparse image), v3 below: 26 B; against 4n^2 flop/pixel -> 7.8 flop/B at n = 64, under the
 // f64 ridge of ~9.8 flop/B (78.6 TF / 8 TB/s); at n = 21 it is 2.5 flop/B.
 #include "swk_internal.h"
 
@@ -258,6 +258,257 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
             b.zzpart[(int64_t)w * b.nblk + blockIdx.x] =
                 ((lds[NPAD * NPAD] + lds[NPAD * NPAD + 1]) + lds[NPAD * NPAD + 2]) + lds[NPAD * NPAD + 3];
     }
+}
+
+// ---------------------------------------------------------------------------------
+// v3: the same pass on HALF the f64 state.  With A_k = M_k B_k (:290) the multiplier update (:294) collapses:
+//   Y_k = Y_{k-1} + mu_{k-1} (X - A_k - E_k)  and  M_k = X - E_k + Y_{k-1}/mu_{k-1}   =>   Y_k = mu_{k-1} (M_k - A_k),
+// so A_k and Y_k are both functions of M_k and the small matrix B_k, and M_k alone (8 B/element) is the state
+// carried between passes instead of A and Y (16 B).  Per pass and element:
+//   read  X u8, M_k f64, U_{k-1} f32      write  M_{k+1} f64, U_k f32, clip(-E_{k+1}) u8        = 26 B (v2: 34 B)
+// U = Y/mu is kept in f32 ONLY for the stopping norm ||Z_k||_F, Z_k = X - A_k - E_k = (M_k - A_k) - U_{k-1} (:293,
+// :297): |U| <~ 100, so its f32 rounding (<= 4e-6 early, ~1e-8 near convergence) perturbs ||Z||^2 by < 1e-6
+// relative; the state itself never sees the rounded value (U_k is recomputed in f64 from M_k).
+// The sparse image has to come from an exact E: pass k computes E_{k+1} exactly (it builds M_{k+1} from it) and
+// writes its u8 form to S[k & 1]; when iteration K turns out to be the last, E_K is what pass K-1 left in
+// S[(K-1) & 1] (k_select_sparse moves it to S[0] for odd K-1).  A and E in f64 are not produced: callers that ask
+// for them run v2.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float buf_ld32f(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st32f(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+
+template <int NB, int MODE, bool FULL>
+__global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
+{
+    using C = V2Cfg<NB>;
+    constexpr int NPAD = C::NPAD, NK = C::NK, BP = C::BP, TP = C::TP;
+    extern __shared__ double lds[];
+    double *sB = lds;                                             // [NPAD][BP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *sT = lds + NPAD * BP + wave * (NPAD * TP);           // this wave's [NPAD][TP]
+    const int w = blockIdx.y;
+    const IalmWin &st = b.win[w];
+    if (st.done) return;
+    const int n = b.n, P = b.P;
+    const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
+    const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
+    const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
+    const double dual = st.dual_norm;
+    const int felems = b.fpad * (int)ps32;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)((sel ? b.Salt : b.S) + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)(b.A + (int64_t)w * b.fpad * b.pstride), 0, felems * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)(b.U + (int64_t)w * b.fpad * b.pstride), 0, felems * 4, 0x00020000);
+
+    double *sY0 = lds + NPAD * BP + 4 * NPAD * TP;
+    if (MODE != 2) sY0[tid] = (double)tid / dual;                 // Y0 = X / dual_norm (:272): 256 possible values
+    if (MODE != 0) {
+        const double *Bm = b.Bm + (int64_t)w * n * n;
+        for (int i = tid; i < NPAD * NPAD; i += 256) {
+            const int k = i / NPAD, c = i % NPAD;
+            sB[k * BP + c] = (k < n && c < n) ? Bm[k * n + c] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    const int pl = lane & 15, fr0 = lane >> 4;
+    const int flim = n - fr0;
+    d4 G[C::NPAIR];
+#pragma unroll
+    for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double zz = 0.0;
+
+    const int ntiles = (P + 15) >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const unsigned p = (unsigned)(tile * 16 + pl);
+        const bool pvalid = p < P32;
+        const unsigned vo8 = pvalid ? ((unsigned)fr0 * ps32 + p) * 8u : kOob;     // f64 planes
+        const unsigned vo4 = pvalid ? ((unsigned)fr0 * ps32 + p) * 4u : kOob;     // f32 planes
+        const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
+        int xi[NK];
+        double mv[NK];
+        float uf[NK];
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            const bool fvalid = FULL || 4 * t < flim;
+            xi[t] = buf_ld8(rX, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
+            if (MODE == 2) {
+                mv[t] = buf_ld64(rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
+                uf[t] = buf_ld32f(rU, fvalid ? vo4 : kOob, (unsigned)(4 * t) * ps32 * 4u);
+            }
+        }
+        if (MODE == 1) {
+            // first iteration: A_0 = 0 (:273) and Y_0 = X / dual (:272), so M_1 is a function of X alone
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                const double x = (double)xi[t];
+                const double u0 = inv_mu * sY0[xi[t]];
+                const double e = shrink2(x + u0, thr);                             // :282-283
+                mv[t] = (x - e) + u0;                                              // :284
+            }
+        }
+#pragma unroll
+        for (int bq0 = 0; bq0 < NB; bq0 += 2) {
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            if (MODE != 0) {
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (bq0 + h < NB) {
+                            const double bop = sB[(4 * t + fr0) * BP + 16 * (bq0 + h) + pl];
+                            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc[h], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (bq0 + h >= NB) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * (bq0 + h) + r;
+                    const double x = (double)xi[t];
+                    double a_new, y;
+                    if (MODE == 0) {
+                        a_new = 0.0;
+                        y = sY0[xi[t]];
+                    } else {
+                        a_new = acc[h][r];                                             // :290
+                        const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}
+                        const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * sY0[xi[t]];
+                        const double z = pk - uprev;                                   // :293
+                        zz += z * z;
+                        y = mu * pk;                                                   // :294
+                    }
+                    const double u = inv_mu2 * y;
+                    const double e2 = shrink2((x - a_new) + u, thr2);
+                    const double m2 = (x - e2) + u;
+                    sT[(4 * t + fr0) * TP + pl] = m2;
+                    const bool fvalid = FULL || 4 * t < flim;
+                    buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
+                    buf_st32f((float)u, rU, fvalid ? vo4 : kOob, (unsigned)(4 * t) * ps32 * 4u);
+                    buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            double tr[NB];
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) tr[fb] = sT[(16 * fb + pl) * TP + 4 * g + fr0];
+            int pair = 0;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB; ++jb) {
+                    G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ib], tr[jb], G[pair], 0, 0, 0);
+                    ++pair;
+                }
+        }
+    }
+
+    __syncthreads();
+    double *sG = lds;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+            int pair = 0;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB; ++jb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ib + fr0 + 4 * r, j = 16 * jb + pl;
+                        if (wv == 0) sG[i * NPAD + j] = G[pair][r];
+                        else sG[i * NPAD + j] += G[pair][r];
+                    }
+                    ++pair;
+                }
+        }
+        __syncthreads();
+    }
+    double *gp = b.gpart + ((int64_t)w * b.nblk + blockIdx.x) * n * n;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        if ((i >> 4) <= (j >> 4)) gp[idx] = sG[i * NPAD + j];
+    }
+    if (MODE != 0) {
+        for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
+        __syncthreads();
+        if (lane == 0) lds[NPAD * NPAD + wave] = zz;
+        __syncthreads();
+        if (tid == 0)
+            b.zzpart[(int64_t)w * b.nblk + blockIdx.x] =
+                ((lds[NPAD * NPAD] + lds[NPAD * NPAD + 1]) + lds[NPAD * NPAD + 2]) + lds[NPAD * NPAD + 3];
+    }
+}
+
+// the last iteration's sparse image sits in S[(iter-1) & 1]: bring the odd ones to S[0]
+__global__ __launch_bounds__(256) void k_select_sparse(IalmBuffers b)
+{
+    const int w = blockIdx.y;
+    const int it = b.win[w].iter;
+    if (it < 1 || (((it - 1) & 1) == 0)) return;
+    const int64_t total = (int64_t)b.n * b.P;
+    const uint8_t *src = b.Salt + (int64_t)w * total;
+    uint8_t *dst = b.S + (int64_t)w * total;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if ((total & 15) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+        const int64_t nv = total >> 4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride)
+            ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) dst[i] = src[i];
+    }
+}
+
+template <int NB, int MODE, bool FULL>
+static void launch3_full(hipStream_t s, const IalmBuffers &b, int sel)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v3<NB, MODE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)V2Cfg<NB>::lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_ialm_pass_v3<NB, MODE, FULL>), dim3(b.nblk, b.nwin), dim3(256), V2Cfg<NB>::lds_bytes, s, b, sel);
+}
+
+template <int NB>
+static void launch3_nb(hipStream_t s, const IalmBuffers &b, int mode, int sel)
+{
+    const bool full = b.n == 16 * NB;
+    if (mode == 0) { if (full) launch3_full<NB, 0, true>(s, b, sel); else launch3_full<NB, 0, false>(s, b, sel); }
+    else if (mode == 1) { if (full) launch3_full<NB, 1, true>(s, b, sel); else launch3_full<NB, 1, false>(s, b, sel); }
+    else { if (full) launch3_full<NB, 2, true>(s, b, sel); else launch3_full<NB, 2, false>(s, b, sel); }
+}
+
+void launch_ialm_pass_v3(hipStream_t s, const IalmBuffers &b, int mode, int k)
+{
+    const int nb = (b.n + 15) / 16;
+    const int sel = k & 1;
+    switch (nb) {
+    case 1: launch3_nb<1>(s, b, mode, sel); break;
+    case 2: launch3_nb<2>(s, b, mode, sel); break;
+    case 3: launch3_nb<3>(s, b, mode, sel); break;
+    default: launch3_nb<4>(s, b, mode, sel); break;
+    }
+}
+
+void launch_select_sparse(hipStream_t s, const IalmBuffers &b)
+{
+    const int64_t total = (int64_t)b.n * b.P;
+    int bx = (int)((total / 16 + 255) / 256);
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_select_sparse, dim3(bx, b.nwin), dim3(256), 0, s, b);
 }
 
 bool ialm_v2_supported(int n) { return n >= 1 && n <= kMaxN; }

@@ -18,7 +18,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_TILEFLAGS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_TILEFLAGS, SL_SALT, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -232,13 +232,16 @@ int ensure_ccl(swk_ctx *ctx, int F, int H, int W, CclBuffers *b)
 
 // ---- IALM driver ----------------------------------------------------------------------
 int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmbda, double tol, int maxiter,
-             bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/)
+             bool want_A, bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/)
 {
     if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
+    // auto: the M-state pass (v3, 26 B/element) unless the caller wants the f64 low-rank / sparse matrices,
+    // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = ctx->ialm_variant;
-    if (variant == 0) variant = 2;
+    if (variant == 0) variant = 3;
+    if (variant == 3 && (want_A || want_E)) variant = 2;
     // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
     // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
     // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
@@ -256,6 +259,10 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     const size_t felems = (size_t)nwin * b.fpad * b.pstride;
     NEED(ctx, SL_A, felems * 8, b.A);
     NEED(ctx, SL_Y, felems * 8, b.Y);
+    if (variant == 3) {
+        b.U = (float *)b.Y;                  // f32 planes in the Y slot
+        NEED(ctx, SL_SALT, elems, b.Salt);
+    }
     if (want_E) NEED(ctx, SL_E, felems * 8, b.E);
     NEED(ctx, SL_BM, (size_t)nwin * n * n * 8, b.Bm);
     NEED(ctx, SL_VPREV, (size_t)nwin * n * n * 8, b.Vprev);
@@ -267,10 +274,14 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     HIPCHK(ctx, hipMemsetAsync(b.win, 0, (size_t)nwin * sizeof(IalmWin), s));
     HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16 * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
-    // a window that stops before writing A (all-zero input) must still read back zeros
-    HIPCHK(ctx, hipMemsetAsync(b.A, 0, felems * 8, s));
-    // padded frame planes (n..fpad-1) of Y are read by the MFMA pass and must contribute zeros
-    if (b.fpad != n) HIPCHK(ctx, hipMemsetAsync(b.Y, 0, felems * 8, s));
+    if (variant == 3) {
+        HIPCHK(ctx, hipMemsetAsync(b.Salt, 0, elems, s));
+    } else {
+        // a window that stops before writing A (all-zero input) must still read back zeros
+        HIPCHK(ctx, hipMemsetAsync(b.A, 0, felems * 8, s));
+        // padded frame planes (n..fpad-1) of Y are read by the MFMA pass and must contribute zeros
+        if (b.fpad != n) HIPCHK(ctx, hipMemsetAsync(b.Y, 0, felems * 8, s));
+    }
     if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, felems * 8, s));
 
     // Window groups.  The eigen-solve of a window runs on ONE compute unit for about a millisecond;
@@ -298,6 +309,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         gr.b.S = b.S + (size_t)w0 * n * P;
         gr.b.A = b.A + (size_t)w0 * b.fpad * b.pstride;
         gr.b.Y = b.Y + (size_t)w0 * b.fpad * b.pstride;
+        gr.b.U = b.U ? b.U + (size_t)w0 * b.fpad * b.pstride : nullptr;
+        gr.b.Salt = b.Salt ? b.Salt + (size_t)w0 * n * P : nullptr;
         gr.b.E = b.E ? b.E + (size_t)w0 * b.fpad * b.pstride : nullptr;
         gr.b.Bm = b.Bm + (size_t)w0 * n * n;
         gr.b.Vprev = b.Vprev + (size_t)w0 * n * n;
@@ -311,7 +324,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, grp[g].b); launch_ialm_init(s, grp[g].b, lmbda); }
         // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
         // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
-        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant); }
+        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
         { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]);
@@ -334,7 +347,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             if (k > maxiter) { gr.finished = true; continue; }
             any = true;
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
-            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant); }
+            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant, k); }
             HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
             hipStream_t gs = ctx->gstream[g];
             HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
@@ -351,6 +364,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     }
     // everything after the IALM runs on the main stream: join the side streams
     for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
+    if (variant == 3) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
     ctx->last_win = b.win;
     ctx->last_nwin = nwin;
     (void)h_iters; (void)d_iters;
@@ -492,7 +506,7 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters)
 }
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 2) return SWK_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 3) return SWK_ERR_ARG;
     ctx->ialm_variant = variant;
     return SWK_OK;
 }
@@ -574,7 +588,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
 
     { Timed t(ctx, SWK_K_GRAY); launch_gray(s, dframes, in->channels, fs, rs, x0, y0, F, H, W, p->gray_mode, dX); }
 
-    rc = run_ialm(ctx, dX, in->nwin, in->n, P, p->lmbda, p->tol, p->maxiter, out->E != nullptr, dS,
+    rc = run_ialm(ctx, dX, in->nwin, in->n, P, p->lmbda, p->tol, p->maxiter, out->A != nullptr, out->E != nullptr, dS,
                   (!dev_out) ? out->iters : nullptr, dev_out ? out->iters : nullptr);
     if (rc) return rc;
 
@@ -663,7 +677,7 @@ int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P, doub
     NEED(ctx, SL_X, elems, dX);
     NEED(ctx, SL_S, elems, dS);
     HIPCHK(ctx, hipMemcpyAsync(dX, planes, elems, hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_ialm(ctx, dX, 1, n, P, lmbda, tol, maxiter, E != nullptr, dS, iters, nullptr);
+    int rc = run_ialm(ctx, dX, 1, n, P, lmbda, tol, maxiter, A != nullptr, E != nullptr, dS, iters, nullptr);
     if (rc) return rc;
     for (int which = 0; which < 2; ++which) {
         double *dst = which == 0 ? A : E;

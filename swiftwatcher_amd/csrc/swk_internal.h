@@ -26,6 +26,8 @@ struct IalmBuffers {
     const uint8_t *X;              // [nwin][n][P]
     double *A, *Y;                 // [nwin][n][P]
     uint8_t *S;                    // [nwin][n][P]
+    uint8_t *Salt;                 // v3: second sparse-image buffer (iteration parity), else null
+    float *U;                      // v3: Y/mu in f32 for the stopping norm, planes like A; b.A holds M
     double *E;                     // optional [nwin][n][P]
     double *Bm;                    // [nwin][n][n]   I - W/mu
     double *Vprev;                 // [nwin][n][n]   eigenvectors of the previous solve (warm start)
@@ -42,7 +44,9 @@ struct IalmBuffers {
 // ialm.hip
 void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
-void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant);
+// k = iteration number of the pass (0 = Gram-only start pass); variant 3 = M-state pass (no A/E outputs)
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k);
+void launch_select_sparse(hipStream_t s, const IalmBuffers &b);
 // method: 0 = Newton-Schulz on the f64 matrix cores (Jacobi only as fallback), 1 = cyclic Jacobi
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);
 // sums the nblk Gram partial slabs of every live window into slab 0, in fixed order, chip-wide

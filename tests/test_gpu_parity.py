@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 ATOL_AE = 1e-5
 
 
-@pytest.fixture(scope="module", params=[(2, 0), (1, 1), (2, 1)], ids=["mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi"])
+@pytest.fixture(scope="module", params=[(0, 0), (2, 0), (1, 1), (2, 1)],
+                ids=["auto_pass+newton_schulz", "mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi"])
 def ctx(request):
-    """Every test runs against both IALM pass kernels (2 = MFMA f64, the default; 1 = LDS/VALU) and both
-    G^(-1/2) solvers (0 = Newton-Schulz on MFMA, the default; 1 = cyclic Jacobi)."""
+    """Every test runs against the IALM pass kernels (0 = auto: the M-state MFMA pass, or the A/Y-state one when
+    A / E are requested; 2 = A/Y-state MFMA pass; 1 = LDS/VALU) and both G^(-1/2) solvers (0 = Newton-Schulz on
+    MFMA, the default; 1 = cyclic Jacobi)."""
     from swiftwatcher_amd import _lib
     c = _lib.Context(0)
     c.set_ialm_variant(request.param[0])
@@ -166,6 +168,38 @@ def test_ialm_golden(ctx, orc, golden_dir, name, atol):
     np.testing.assert_allclose(E[rows], g["E_rows"], atol=atol, rtol=0)
     np.testing.assert_allclose(A.sum(axis=0), g["A_colsum"], rtol=1e-8)
     np.testing.assert_array_equal(ctx.rpca_epilogue(E).T.reshape(n, H, W), g["sparse"])
+
+
+@pytest.mark.parametrize("name", ["ialm_128x160x7", "ialm_64x96x21", "ialm_64x96x64", "ialm_107x214x21", "ialm_40x48x64"])
+def test_sparse_image_golden_without_float_outputs(ctx, golden_dir, name):
+    """The hot path asks for neither A nor E: the default (M-state) pass must still deliver the reference's
+    sparse u8 image and iteration count bit for bit."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    frames = g["frames"]
+    n = frames.shape[0]
+    res = ctx.batch_run(frames, 1, n, stages=("gray", "rpca"))
+    assert int(res["iters"][0]) == int(g["iters"])
+    np.testing.assert_array_equal(res["gray"], frames)
+    np.testing.assert_array_equal(res["rpca"], g["sparse"])
+
+
+def test_pass_kernels_agree_at_full_size():
+    """424x212 x 64 frames, four windows with different content: the M-state pass (26 B/element) and the
+    A/Y-state pass (34 B/element) give the same iteration counts, sparse images, labels and regions."""
+    from swiftwatcher_amd import _lib, synthetic
+    roi = np.concatenate([synthetic.roi_window(70 + w, 64, 212, 424, birds=4 + 5 * w) for w in range(4)])
+    out = []
+    for variant in (3, 2):
+        c = _lib.Context(0)
+        c.set_ialm_variant(variant)
+        out.append(c.batch_run(roi, 4, 64, stages=("rpca", "opened", "labels")))
+        c.close()
+    a, b = out
+    np.testing.assert_array_equal(a["iters"], b["iters"])
+    assert len(set(int(i) & 1 for i in a["iters"])) >= 1
+    for key in ("rpca", "opened", "labels", "nseg"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert a["segs"].tobytes() == b["segs"].tobytes()
 
 
 def test_ialm_vs_oracle_and_null_frames(ctx, orc):
