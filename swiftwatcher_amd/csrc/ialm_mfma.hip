@@ -306,8 +306,13 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)(b.A + (int64_t)w * b.fpad * b.pstride), 0, felems * 8, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)(b.U + (int64_t)w * b.fpad * b.pstride), 0, felems * 4, 0x00020000);
 
-    double *sY0 = lds + NPAD * BP + 4 * NPAD * TP;
-    if (MODE != 2) sY0[tid] = (double)tid / dual;                 // Y0 = X / dual_norm (:272): 256 possible values
+    // Y0 = X / dual_norm (:272) for the first two passes: the quotient of a small integer, formed in registers
+    // as one Newton step on x * (1/dual) -- the correctly rounded x / dual without a per-element division
+    const double rdual = 1.0 / dual;
+    auto y0_of = [&](double x) {
+        const double q = x * rdual;
+        return __builtin_fma(__builtin_fma(-q, dual, x), rdual, q);
+    };
     if (MODE != 0) {
         const double *Bm = b.Bm + (int64_t)w * n * n;
         for (int i = tid; i < NPAD * NPAD; i += 256) {
@@ -324,8 +329,13 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
     double zz = 0.0;
 
+    // a block owns groups of 8 consecutive tiles = 128 pixels: every 128-byte line of the u8 planes (and every
+    // pair of half lines of the f32 plane) is touched by ONE workgroup, two tiles per wave back to back
     const int ntiles = (P + 15) >> 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int nsteps = 2 * ((((ntiles + 7) >> 3) - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    for (int it = 0; it < nsteps; ++it) {
+        const int tile = ((int)blockIdx.x + (it >> 1) * (int)gridDim.x) * 8 + wave * 2 + (it & 1);
+        if (tile >= ntiles) continue;
         const unsigned p = (unsigned)(tile * 16 + pl);
         const bool pvalid = p < P32;
         const unsigned vo8 = pvalid ? ((unsigned)fr0 * ps32 + p) * 8u : kOob;     // f64 planes
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
 #pragma unroll
             for (int t = 0; t < NK; ++t) {
                 const double x = (double)xi[t];
-                const double u0 = inv_mu * sY0[xi[t]];
+                const double u0 = inv_mu * y0_of(x);
                 const double e = shrink2(x + u0, thr);                             // :282-283
                 mv[t] = (x - e) + u0;                                              // :284
             }
@@ -378,11 +388,11 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                     double a_new, y;
                     if (MODE == 0) {
                         a_new = 0.0;
-                        y = sY0[xi[t]];
+                        y = y0_of(x);
                     } else {
                         a_new = acc[h][r];                                             // :290
                         const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}
-                        const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * sY0[xi[t]];
+                        const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * y0_of(x);
                         const double z = pk - uprev;                                   // :293
                         zz += z * z;
                         y = mu * pk;                                                   // :294
@@ -392,8 +402,10 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                     const double m2 = (x - e2) + u;
                     sT[(4 * t + fr0) * TP + pl] = m2;
                     const bool fvalid = FULL || 4 * t < flim;
-                    buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
-                    buf_st32f((float)u, rU, fvalid ? vo4 : kOob, (unsigned)(4 * t) * ps32 * 4u);
+                    if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
+                        buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
+                        buf_st32f((float)u, rU, fvalid ? vo4 : kOob, (unsigned)(4 * t) * ps32 * 4u);
+                    }
                     buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
                 }
             }
