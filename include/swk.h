@@ -180,6 +180,12 @@ int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, i
 int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
                              const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
                              uint8_t *patches, float *net, int32_t net_mem);
+/* Same, writing only the centred (24 + 2 pad)^2 window of each 224x224 input: net is [nseg][3][24+2pad][24+2pad].
+ * pad = 100 is swk_classifier_input; pad = 8 (rows/cols 92..131) is all the receptive-field cropped network of
+ * swiftwatcher_amd/segment_classification.py reads. */
+int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
+                                    const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
+                                    int32_t pad, uint8_t *patches, float *net, int32_t net_mem);
 
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size

@@ -80,6 +80,7 @@ _SIGS = {
     "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
@@ -297,9 +298,10 @@ class Context:
                                          label_order, _ptr(lab), _ptr(nc)))
         return (int(nc[0]), lab[0]) if single else (nc, lab)
 
-    def classifier_input(self, crops, mean, std, want_patches=False, net_ptr=None):
-        """swk_classifier_input for a list of HxWx3 uint8 crops.  Returns (patches or None, net or None):
-        net is a float32 host array (n, 3, 224, 224) unless net_ptr (a device pointer with room for it) is given."""
+    def classifier_input(self, crops, mean, std, want_patches=False, net_ptr=None, pad=100):
+        """swk_classifier_input_window for a list of HxWx3 uint8 crops.  Returns (patches or None, net or None):
+        net is a float32 host array (n, 3, S, S), S = 24 + 2 pad, unless net_ptr (a device pointer with room for
+        it) is given.  pad = 100 is the reference's full 224x224 input."""
         n = len(crops)
         flat = [np.ascontiguousarray(c, np.uint8).reshape(-1) for c in crops]
         sizes = np.array([f.size for f in flat], np.int64)
@@ -311,12 +313,12 @@ class Context:
         patches = np.empty((n, 24, 24, 3), np.uint8) if want_patches else None
         net = None
         if net_ptr is None:
-            net = np.empty((n, 3, 224, 224), np.float32)
+            net = np.empty((n, 3, 24 + 2 * pad, 24 + 2 * pad), np.float32)
             nptr, nmem = _ptr(net), MEM_HOST
         else:
             nptr, nmem = ctypes.c_void_p(net_ptr), MEM_DEVICE
-        self._check(self._lib.swk_classifier_input(self._h, _ptr(packed), packed.size, _ptr(offsets), _ptr(hw), n,
-                                                   _ptr(m), _ptr(s), _ptr(patches), nptr, nmem))
+        self._check(self._lib.swk_classifier_input_window(self._h, _ptr(packed), packed.size, _ptr(offsets), _ptr(hw), n,
+                                                          _ptr(m), _ptr(s), int(pad), _ptr(patches), nptr, nmem))
         return patches, net
 
     def regionprops_u8(self, labels, seg_cap=255):

@@ -10,8 +10,7 @@
 namespace swk {
 
 constexpr int kOut = 24;                       // Resize((24, 24))
-constexpr int kPad = 100;                      // Pad((224 - 24) // 2)
-constexpr int kNet = 224;
+
 constexpr int kMaxIn = 512;                    // largest crop side handled
 constexpr int kMaxK = 2 * ((kMaxIn + kOut - 1) / kOut) + 1;     // coefficients per output sample
 constexpr int kPrecision = 22;                 // 32 - 8 - 2 bits
@@ -54,7 +53,7 @@ __device__ __forceinline__ int clip8(int v)
 
 __global__ __launch_bounds__(256) void k_classifier_input(const uint8_t *__restrict__ crops, const int64_t *__restrict__ offsets,
                                                           const int32_t *__restrict__ hw, uint8_t *__restrict__ patches,
-                                                          float *__restrict__ net, float m0, float m1, float m2,
+                                                          float *__restrict__ net, int pad, float m0, float m1, float m2,
                                                           float s0, float s1, float s2)
 {
     __shared__ int s_kx[kOut * kMaxK], s_ky[kOut * kMaxK];
@@ -107,24 +106,27 @@ __global__ __launch_bounds__(256) void k_classifier_input(const uint8_t *__restr
     if (patches)
         for (int i = tid; i < kOut * kOut * 3; i += 256) patches[(int64_t)seg * kOut * kOut * 3 + i] = s_out[i];
     if (net) {
-        // Pad(100) with zeros, ToTensor (/255), Normalize ((t - mean) / std): the border is the constant (0 - mean)/std
+        // Pad(100) with zeros, ToTensor (/255), Normalize ((t - mean) / std): the border is the constant (0 - mean)/std.
+        // pad = 100 writes the whole 224x224 input; a smaller pad writes the centred (24 + 2 pad)^2 window of it
+        // (the receptive-field cropped network reads rows/cols 92..131 only: pad = 8).
         const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
-        float *o = net + (int64_t)seg * 3 * kNet * kNet;
-        for (int i = tid; i < 3 * kNet * kNet; i += 256) {
-            const int c = i / (kNet * kNet), rem = i - c * kNet * kNet;
-            const int y = rem / kNet, x = rem - y * kNet;
+        const int side = kOut + 2 * pad;
+        float *o = net + (int64_t)seg * 3 * side * side;
+        for (int i = tid; i < 3 * side * side; i += 256) {
+            const int c = i / (side * side), rem = i - c * side * side;
+            const int y = rem / side, x = rem - y * side;
             float v = 0.0f;
-            if (y >= kPad && y < kPad + kOut && x >= kPad && x < kPad + kOut)
-                v = (float)s_out[((y - kPad) * kOut + (x - kPad)) * 3 + c] / 255.0f;
+            if (y >= pad && y < pad + kOut && x >= pad && x < pad + kOut)
+                v = (float)s_out[((y - pad) * kOut + (x - pad)) * 3 + c] / 255.0f;
             o[i] = (v - mean[c]) / sd[c];
         }
     }
 }
 
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
-                             uint8_t *patches, float *net, const float *mean, const float *sd)
+                             uint8_t *patches, float *net, int pad, const float *mean, const float *sd)
 {
-    hipLaunchKernelGGL(k_classifier_input, dim3(nseg), dim3(256), 0, s, crops, offsets, hw, patches, net,
+    hipLaunchKernelGGL(k_classifier_input, dim3(nseg), dim3(256), 0, s, crops, offsets, hw, patches, net, pad,
                        mean[0], mean[1], mean[2], sd[0], sd[1], sd[2]);
 }
 

@@ -795,11 +795,12 @@ int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, i
     return sync(ctx);
 }
 
-int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
-                             const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
-                             uint8_t *patches, float *net, int32_t net_mem)
+int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
+                                    const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
+                                    int32_t pad, uint8_t *patches, float *net, int32_t net_mem)
 {
-    if (!ctx || !crops || !offsets || !hw || !mean || !std_ || nseg < 1 || crops_bytes < 1 || (!patches && !net))
+    if (!ctx || !crops || !offsets || !hw || !mean || !std_ || nseg < 1 || crops_bytes < 1 || (!patches && !net) ||
+        pad < 0 || pad > 100)
         return fail(ctx, SWK_ERR_ARG, "bad argument");
     for (int i = 0; i < nseg; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
@@ -816,12 +817,20 @@ int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_b
     HIPCHK(ctx, hipMemcpyAsync(doffs, offsets, (size_t)nseg * 8, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(dhw, hw, (size_t)nseg * 8, hipMemcpyHostToDevice, s));
     if (patches) NEED(ctx, SL_CL_PATCH, (size_t)nseg * 24 * 24 * 3, dpatch);
-    const size_t net_bytes = (size_t)nseg * 3 * 224 * 224 * sizeof(float);
+    const size_t side = 24 + 2 * (size_t)pad;
+    const size_t net_bytes = (size_t)nseg * 3 * side * side * sizeof(float);
     if (net) { if (net_mem == SWK_MEM_DEVICE) dnet = net; else NEED(ctx, SL_CL_NET, net_bytes, dnet); }
-    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, mean, std_);
+    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, pad, mean, std_);
     if (patches) HIPCHK(ctx, hipMemcpyAsync(patches, dpatch, (size_t)nseg * 24 * 24 * 3, hipMemcpyDeviceToHost, s));
     if (net && net_mem != SWK_MEM_DEVICE) HIPCHK(ctx, hipMemcpyAsync(net, dnet, net_bytes, hipMemcpyDeviceToHost, s));
     return sync(ctx);
+}
+
+int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
+                             const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
+                             uint8_t *patches, float *net, int32_t net_mem)
+{
+    return swk_classifier_input_window(ctx, crops, crops_bytes, offsets, hw, nseg, mean, std_, 100, patches, net, net_mem);
 }
 
 }  // extern "C"

@@ -76,7 +76,7 @@ size_t filter_flags_bytes(int F, int H, int W);
 
 // classify_input.hip
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
-                             uint8_t *patches, float *net, const float *mean, const float *sd);
+                             uint8_t *patches, float *net, int pad, const float *mean, const float *sd);
 
 // ccl.hip
 struct CclBuffers {

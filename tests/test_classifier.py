@@ -65,6 +65,59 @@ def test_cpu_device_matches_oracle(tmp_path):
     assert clf([]) == []
 
 
+def test_cropped_network_equals_full_network(tmp_path):
+    """Receptive-field cropped evaluation: same scores as the full 224x224 forward to float32
+    summation order, and the oracle's decisions, on the CPU kernels."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    rng = np.random.default_rng(8)
+    segs = _segments(rng, 24)
+    imgs = [s.segment_image for s in segs]
+    sd = ref.calibrate_head(ref.random_state_dict(6), imgs)
+    path = tmp_path / "w.pt"
+    torch.save(sd, path)
+    full = SegmentClassifier(str(path), device="cpu", cropped=False)
+    crop = SegmentClassifier(str(path), device="cpu", batch_size=7)            # ragged last batch
+    assert crop.cropped is not None and full.cropped is None
+    a, b = full.scores(imgs).numpy(), crop.scores(imgs).numpy()
+    np.testing.assert_allclose(b, a, atol=2e-6, rtol=1e-5)
+    exp_scores, exp_keep = ref.classify(sd, imgs)
+    np.testing.assert_allclose(b, exp_scores, atol=2e-4, rtol=1e-4)
+    # the window the cropped network reads is exactly rows/cols 92..131 of the full input
+    x_full, x_win = full.preprocess(imgs[:5]), crop.preprocess(imgs[:5], window=True)
+    assert x_win.shape == (5, 3, 40, 40) and torch.equal(x_win, x_full[:, :, 92:132, 92:132])
+    # and nothing outside it may matter: geometry recorded by the plan
+    assert crop.cropped.final == (1, 11, 13)
+    assert [tuple(p[2].shape[1:]) for p in crop.cropped.plan] == [
+        (96, 12, 12), (128, 14, 14), (128, 16, 16), (256, 17, 17), (256, 12, 12), (256, 14, 14), (384, 16, 16),
+        (384, 18, 18), (512, 19, 19), (512, 13, 13)]
+
+
+@pytest.mark.gpu
+def test_gpu_cropped_and_full_paths_agree(tmp_path):
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    rng = np.random.default_rng(9)
+    segs = _segments(rng, 64)
+    imgs = [s.segment_image for s in segs]
+    sd = ref.calibrate_head(ref.random_state_dict(7), imgs)
+    path = tmp_path / "w.pt"
+    torch.save(sd, path)
+    full = SegmentClassifier(str(path), cropped=False)
+    crop = SegmentClassifier(str(path))
+    a, b = full.scores(imgs).cpu().numpy(), crop.scores(imgs).cpu().numpy()
+    np.testing.assert_allclose(b, a, atol=2e-5, rtol=1e-4)
+    x_full, x_win = full.preprocess(imgs[:9]), crop.preprocess(imgs[:9], window=True)
+    assert torch.equal(x_win, x_full[:, :, 92:132, 92:132])                  # HIP window kernel, bit-exact
+    exp_scores, exp_keep = ref.classify(sd, imgs)
+    np.testing.assert_allclose(b, exp_scores, atol=2e-4, rtol=1e-4)
+    margin = np.abs(exp_scores[:, 1] - exp_scores[:, 0]) > 2e-3
+    kept_ids = {id(s) for s in crop(segs)}
+    for s, k, m in zip(segs, exp_keep, margin):
+        if m:
+            assert (id(s) in kept_ids) == bool(k)
+
+
 @pytest.mark.gpu
 def test_gpu_scores_and_decisions_match_oracle(tmp_path):
     from swiftwatcher_amd.segment_classification import SegmentClassifier
