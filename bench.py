@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
+    ap.add_argument("--classify", action="store_true",
+                    help="also classify every segment inside the timed step (SqueezeNet-1.0 on PyTorch-ROCm, random-init "
+                         "weights, inputs cut on the device by swk_segment_inputs): BASELINE config 3 without the tracker")
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
     ap.add_argument("--eig-method", type=int, default=0, help="0 Newton-Schulz (MFMA), 1 Jacobi")
@@ -118,8 +121,21 @@ def main():
     out.nseg = nseg.data_ptr()
     out.iters = iters.data_ptr()
 
+    clf = None
+    kept_total = [0, 0]
+    if args.classify:
+        from swiftwatcher_amd.segment_classification import SegmentClassifier, SqueezeNet10
+        torch.manual_seed(20190816)
+        clf = SegmentClassifier.from_state_dict(SqueezeNet10(2).state_dict(), device=dev, batch_size=2048)
+
     def step():
         ctx.batch_run_raw(inp, params, out)      # synchronous on the library's own stream
+        if clf is not None:
+            scores, fidx = clf.scores_from_device(ctx, inp, (Hc, Wc), segs, nseg, seg_cap)
+            keep = torch.max(scores, 1)[1] == 1                      # segment_classification.py:36-39
+            per_frame = torch.bincount(fidx[keep].to(torch.int64), minlength=F)
+            kept_total[0] = int(per_frame.sum().item())
+            kept_total[1] = int(scores.shape[0])
 
     def fence():
         torch.cuda.synchronize()
@@ -166,7 +182,7 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "frames/sec (segment) on 1080p ROI batches",
+            "metric": "frames/sec (segment+classify) on 1080p ROI batches" if clf else "frames/sec (segment) on 1080p ROI batches",
             "value": round(total_frames / dt_max, 2),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,6 +195,9 @@ def main():
                        "roi": [Wc, Hc], "frame_batch": n, "windows_per_step": nwin,
                        "ialm_iters_mean": round(float(it_host.mean()), 2),
                        "segments_per_frame": round(float(nseg_host.mean()), 2),
+                       "classify": ("every segment through SqueezeNet-1.0 (fp32, receptive-field cropped, random-init "
+                                    "weights): %d segments/step, %d kept" % (kept_total[1], kept_total[0])) if clf else
+                                   "not in this config (BASELINE configs[1] is image_filtering only; --classify adds it)",
                        "parallelism": "windows sharded per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -187,6 +187,19 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
                                     const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
                                     int32_t pad, uint8_t *patches, float *net, int32_t net_mem);
 
+/* Classifier inputs cut on the device from the frames and region records of a swk_batch_run with device buffers
+ * (in->mem = SWK_MEM_DEVICE, BGR; segs / nseg / net / seg_frame are device pointers): segment k of the batch is
+ * region i of frame f in frame order.  Its crop box is extract_segment_images' (image_filtering.py:338-369): bbox
+ * grown to at least min_h x min_w (floor / ceil split), translated by (x0, y0), sliced out of the full frame_h x
+ * frame_w frame -- intersected with the frame where the reference's unchecked slice would leave it.  Segments
+ * [first, first + net_cap) get their (24 + 2 pad)^2 network inputs written to net; seg_frame (optional) receives
+ * the frame index of each.  *total = segments in the batch (regions beyond seg_cap per frame do not count);
+ * *skipped = boxes that were empty or larger than 512 pixels (their input is the blank image). */
+int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, int32_t frame_w,
+                           const swk_segment *segs, const int32_t *nseg, int32_t seg_cap, int32_t min_h, int32_t min_w,
+                           const float mean[3], const float std_[3], int32_t pad, int32_t first, int32_t net_cap,
+                           float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped);
+
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size
  * n_prev + n_curr, row-major.  Centroids are (row, col) float64 pairs; prev_hist0 = centroid of the first

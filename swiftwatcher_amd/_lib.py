@@ -80,6 +80,7 @@ _SIGS = {
     "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "swk_segment_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -320,6 +321,22 @@ class Context:
         self._check(self._lib.swk_classifier_input_window(self._h, _ptr(packed), packed.size, _ptr(offsets), _ptr(hw), n,
                                                           _ptr(m), _ptr(s), int(pad), _ptr(patches), nptr, nmem))
         return patches, net
+
+    def segment_inputs(self, inp, frame_hw, segs_ptr, nseg_ptr, seg_cap, mean, std, net_ptr, net_cap, first=0, pad=8,
+                       min_seg_size=(24, 24), seg_frame_ptr=None):
+        """swk_segment_inputs: classifier inputs cut on the device from the frames (inp, device-resident BGR) and the
+        region records of a batch_run with device outputs.  Returns (total segments in the batch, skipped boxes)."""
+        m = np.asarray(mean, np.float32)
+        s = np.asarray(std, np.float32)
+        total = ctypes.c_int32(0)
+        skipped = ctypes.c_int32(0)
+        self._check(self._lib.swk_segment_inputs(self._h, ctypes.byref(inp), int(frame_hw[0]), int(frame_hw[1]),
+                                                 ctypes.c_void_p(segs_ptr), ctypes.c_void_p(nseg_ptr), int(seg_cap),
+                                                 int(min_seg_size[0]), int(min_seg_size[1]), _ptr(m), _ptr(s), int(pad),
+                                                 int(first), int(net_cap), ctypes.c_void_p(net_ptr),
+                                                 ctypes.c_void_p(seg_frame_ptr) if seg_frame_ptr else None,
+                                                 ctypes.byref(total), ctypes.byref(skipped)))
+        return total.value, skipped.value
 
     def regionprops_u8(self, labels, seg_cap=255):
         s, single = self._planes(labels)

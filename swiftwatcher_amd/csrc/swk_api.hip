@@ -18,7 +18,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_TILEFLAGS, SL_SALT, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_TILEFLAGS, SL_SALT, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -824,6 +824,46 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
     if (patches) HIPCHK(ctx, hipMemcpyAsync(patches, dpatch, (size_t)nseg * 24 * 24 * 3, hipMemcpyDeviceToHost, s));
     if (net && net_mem != SWK_MEM_DEVICE) HIPCHK(ctx, hipMemcpyAsync(net, dnet, net_bytes, hipMemcpyDeviceToHost, s));
     return sync(ctx);
+}
+
+int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, int32_t frame_w,
+                           const swk_segment *segs, const int32_t *nseg, int32_t seg_cap, int32_t min_h, int32_t min_w,
+                           const float mean[3], const float std_[3], int32_t pad, int32_t first, int32_t net_cap,
+                           float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped)
+{
+    if (!ctx || !in || !in->frames || !segs || !nseg || !mean || !std_ || !net || !total)
+        return fail(ctx, SWK_ERR_ARG, "bad argument");
+    if (in->mem != SWK_MEM_DEVICE || in->channels != 3) return fail(ctx, SWK_ERR_ARG, "segment inputs are cut from device-resident BGR frames");
+    const int64_t F64 = (int64_t)in->nwin * in->n;
+    if (in->nwin < 1 || in->n < 1 || F64 > (1 << 24) || seg_cap < 1 || pad < 0 || pad > 100 || first < 0 || net_cap < 1 ||
+        frame_h < 1 || frame_w < 1 || min_h < 1 || min_w < 1 || min_h > 512 || min_w > 512 ||
+        in->x0 < 0 || in->y0 < 0 || in->x0 + in->Wc > frame_w || in->y0 + in->Hc > frame_h ||
+        in->row_stride < (int64_t)frame_w * 3 || in->frame_stride < in->row_stride * frame_h)
+        return fail(ctx, SWK_ERR_ARG, "bad geometry");
+    const int F = (int)F64;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int32_t *doffs;
+    NEED(ctx, SL_SEGOFFS, ((size_t)F + 2) * 4, doffs);           // [F+1] prefix sums, then the skipped-box counter
+    int32_t *dskip = doffs + F + 1;
+    HIPCHK(ctx, hipMemsetAsync(dskip, 0, 4, s));
+    launch_segment_prefix(s, nseg, F, seg_cap, doffs);
+    int32_t tot = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&tot, doffs + F, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    *total = tot;
+    if (skipped) *skipped = 0;
+    int count = tot - first;
+    if (count > net_cap) count = net_cap;
+    if (count < 1) return SWK_OK;
+    launch_segment_inputs(s, in->frames, in->frame_stride, in->row_stride, frame_h, frame_w, in->x0, in->y0, segs, doffs, F, seg_cap,
+                          min_h, min_w, first, count, net, seg_frame, pad, mean, std_, dskip);
+    int32_t sk = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&sk, dskip, 4, hipMemcpyDeviceToHost, s));
+    int rc = sync(ctx);
+    if (rc) return rc;
+    if (skipped) *skipped = sk;
+    return SWK_OK;
 }
 
 int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,

@@ -142,28 +142,75 @@ class CroppedSqueezeNet10:
         ring[:, :, lo:hi + 1, lo:hi + 1] = 0
         self.ring_sum = ring.sum(dim=(2, 3))                 # (1, 2): the head's input-independent positions
         self.n_pos = float(size * size)
+        # input-independent squeeze output of every Fire tile (with the map's own zero padding where a tile reaches
+        # the edge): the ring of the persistent squeeze buffers
+        self.sq_bg = []
+        with torch.no_grad():
+            for kind, layer, tile, off, n, pad, crop in self.plan:
+                if kind != "fire":
+                    self.sq_bg.append(None)
+                    continue
+                sq = layer.squeeze_activation(layer.squeeze(tile))
+                if pad[0] or pad[1]:
+                    sq = torch.nn.functional.pad(sq, (pad[0], pad[1], pad[0], pad[1]))
+                self.sq_bg.append(sq.contiguous())
+        self._cap = 0
+        self._buf = None
+
+    def _buffers(self, batch):
+        """Persistent per-layer tiles for up to `batch` segments.  Their rings hold the background values and are
+        written once; a forward pass only overwrites the live centres."""
+        if batch <= self._cap:
+            return self._buf
+        bufs = []
+        for (kind, layer, tile, off, n, pad, crop), sq in zip(self.plan, self.sq_bg):
+            if kind == "fire":
+                bufs.append(sq.expand(batch, -1, -1, -1).contiguous())
+            else:
+                bufs.append(tile.expand(batch, -1, -1, -1).contiguous())
+        # live (ring-free) inputs of the Fires that follow a Fire, and of the head
+        live = []
+        for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
+            nxt = self.plan[j + 1][0] if j + 1 < len(self.plan) else "head"
+            if kind == "fire" and nxt != "pool":
+                c_out = layer.expand1x1.out_channels + layer.expand3x3.out_channels
+                live.append(torch.empty((batch, c_out, crop[1], crop[1]), dtype=torch.float32, device=tile.device))
+            else:
+                live.append(None)
+        self._buf, self._cap = (bufs, live), batch
+        return self._buf
 
     @torch.no_grad()
     def __call__(self, tiles):
         """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input."""
         m = self.model
+        conv2d = torch.nn.functional.conv2d
+        k = tiles.shape[0]
+        bufs, live = self._buffers(k)
         x = torch.relu(m.features[0](tiles))
         a, b = self.pool1_slice
         x = m.features[2](x[:, :, a:b, a:b])
-        for kind, layer, tile, off, n, pad, crop in self.plan:
-            t = tile.expand(x.shape[0], -1, -1, -1).clone()
-            t[:, :, off:off + n, off:off + n] = x
+        for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
             if kind == "pool":
-                x = layer(t)
+                x = layer(bufs[j][:k])                       # centre written by the Fire before it
                 continue
-            sq = layer.squeeze_activation(layer.squeeze(t))
-            e3_in = sq
-            if pad[0] or pad[1]:
-                e3_in = torch.nn.functional.pad(sq, (pad[0], pad[1], pad[0], pad[1]))     # the map's own zero padding
-            e3 = torch.nn.functional.conv2d(e3_in, layer.expand3x3.weight, layer.expand3x3.bias)
+            sq = bufs[j][:k]
+            o = off + pad[0]
+            torch.clamp_min(layer.squeeze(x), 0, out=sq[:, :, o:o + n, o:o + n])
+            e3 = conv2d(sq, layer.expand3x3.weight, layer.expand3x3.bias)            # valid: the halo is in the tile
+            e1 = conv2d(sq, layer.expand1x1.weight, layer.expand1x1.bias)
             c, cn = crop
-            e1 = layer.expand1x1(sq[:, :, c:c + cn, c:c + cn])
-            x = torch.cat([torch.relu(e1), torch.relu(e3)], 1)
+            c1 = layer.expand1x1.out_channels
+            if live[j] is not None:
+                dest = live[j][:k]
+            else:                                            # straight into the centre of the pool tile
+                _, _, _, poff, pn, _, _ = self.plan[j + 1]
+                assert pn == cn
+                dest = bufs[j + 1][:k, :, poff:poff + pn, poff:poff + pn]
+            cp = c + pad[0]
+            torch.clamp_min(e1[:, :, cp:cp + cn, cp:cp + cn], 0, out=dest[:, :c1])
+            torch.clamp_min(e3, 0, out=dest[:, c1:])
+            x = dest
         s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
         return (s + self.ring_sum) / self.n_pos
 
@@ -190,6 +237,15 @@ def resize_segment(segment_image):
 
 class SegmentClassifier:
     """segment_classification.py:14-44."""
+
+    @classmethod
+    def from_state_dict(cls, state, **kw):
+        """Same as the constructor, from an in-memory state_dict (synthetic-weight benchmarks, tests)."""
+        import io
+        buf = io.BytesIO()
+        torch.save(state, buf)
+        buf.seek(0)
+        return cls(buf, **kw)
 
     def __init__(self, model_path, device=None, batch_size=1024, cropped=True):
         if device is None:
@@ -241,6 +297,40 @@ class SegmentClassifier:
             else:
                 out.append(self.model(self.preprocess(chunk)))
         return torch.cat(out) if out else torch.zeros((0, 2), device=self.device)
+
+    @torch.no_grad()
+    def scores_from_device(self, ctx, inp, frame_hw, segs, nseg, seg_cap, min_seg_size=(24, 24)):
+        """The classifier on a whole batch_run without leaving the GPU: inp is the swk_input of that call (device
+        frames), segs / nseg its device region records (torch tensors).  The crops of extract_segment_images
+        (image_filtering.py:338-369) are cut, resized and normalised by swk_segment_inputs into the network's input
+        tensor, batch_size segments at a time.  Returns (scores (T, 2), frame index (T,) int32), both on the device,
+        segments in frame order then ascending label -- the order FrameQueue hands them to __call__."""
+        if self.device.type != "cuda":
+            raise RuntimeError("scores_from_device needs the GPU")
+        pad = PAD - CroppedSqueezeNet10.IN_LO if self.cropped is not None else PAD
+        side = RESIZE + 2 * pad
+        bs = self.batch_size
+        x = torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device)
+        fidx = torch.empty((bs,), dtype=torch.int32, device=self.device)
+        scores, frames_of = [], []
+        first, total = 0, None
+        while total is None or first < total:
+            torch.cuda.synchronize(self.device)          # the library writes x on its own stream
+            total, skipped = ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
+                                                IMAGENET_STD, x.data_ptr(), bs, first=first, pad=pad,
+                                                min_seg_size=min_seg_size, seg_frame_ptr=fidx.data_ptr())
+            if skipped:
+                raise RuntimeError("%d segment boxes were empty or larger than 512 pixels" % skipped)
+            k = min(bs, total - first)
+            if k <= 0:
+                break
+            xb = x[:k]
+            scores.append(self.cropped(xb) if self.cropped is not None else self.model(xb))
+            frames_of.append(fidx[:k].clone())
+            first += k
+        if not scores:
+            return torch.zeros((0, 2), device=self.device), torch.zeros((0,), dtype=torch.int32, device=self.device)
+        return torch.cat(scores), torch.cat(frames_of)
 
     def __call__(self, segments):
         """:26-44: keep segments whose argmax is class 1 (ties / all-zero scores give 0 and are

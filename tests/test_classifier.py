@@ -171,3 +171,71 @@ def test_hip_classifier_input_is_pillow_exact(tmp_path):
     x = clf.preprocess(crops[:9]).cpu()
     for i in range(9):
         assert torch.equal(x[i], ref.transform(crops[i])[0])
+
+
+@pytest.mark.gpu
+def test_device_resident_segment_inputs_match_host_path(tmp_path):
+    """swk_segment_inputs (crop boxes + Pillow resize + normalise, cut from device frames by region records that
+    never left the GPU) against the host path: extract_segment_images on the host frames + swk_classifier_input.
+    Same input tensors bit for bit, so the same scores; frame indices in frame order."""
+    from swiftwatcher_amd import _lib, synthetic
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.segment_classification import SegmentClassifier, IMAGENET_MEAN, IMAGENET_STD
+    from oracle import classifier_ref as ref
+    crop_region = [(40, 30), (40 + 120, 30 + 60)]
+    nwin, n, FH, FW = 2, 21, 128, 200
+    frames = np.concatenate([synthetic.full_frames(300 + w, n, crop_region, frame_hw=(FH, FW), birds=2 + w,
+                                                   bird_len=(28, 45), bird_wid=(10, 18)) for w in range(nwin)])
+    ctx = _lib.Context(0)
+    host = ctx.batch_run(frames, nwin, n, crop=(40, 30, 120, 60), stages=("labels",))
+    imgs, frame_of = [], []
+    for f in range(nwin * n):
+        rps = img.regionprops_from_records(host["segs"][f, :host["nseg"][f]])
+        crops = img.extract_segment_images(rps, frames[f], (24, 24), crop_region)
+        imgs += crops
+        frame_of += [f] * len(crops)
+    assert len(imgs) > 20 and any(c.shape[:2] != (24, 24) for c in imgs)
+    # the same batch with every buffer in HBM
+    dev = torch.device("cuda", 0)
+    dframes = torch.from_numpy(frames).to(dev)
+    seg_cap = 32
+    segs = torch.zeros((nwin * n, seg_cap, 48), dtype=torch.uint8, device=dev)
+    nseg = torch.zeros((nwin * n,), dtype=torch.int32, device=dev)
+    iters = torch.zeros((nwin,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    inp = _lib.Input(frames=dframes.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=60, Wc=120,
+                     x0=40, y0=30, frame_stride=FH * FW * 3, row_stride=FW * 3)
+    out = _lib.Output(mem=_lib.MEM_DEVICE, seg_cap=seg_cap)
+    out.segs, out.nseg, out.iters = segs.data_ptr(), nseg.data_ptr(), iters.data_ptr()
+    ctx.batch_run_raw(inp, _lib.default_params(), out)
+    np.testing.assert_array_equal(nseg.cpu().numpy(), host["nseg"])
+    # raw inputs: full 224 and the 40-pixel window
+    for pad in (100, 8):
+        side = 24 + 2 * pad
+        x = torch.empty((len(imgs), 3, side, side), dtype=torch.float32, device=dev)
+        fidx = torch.empty((len(imgs),), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        total, skipped = ctx.segment_inputs(inp, (FH, FW), segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
+                                            IMAGENET_STD, x.data_ptr(), len(imgs), pad=pad, seg_frame_ptr=fidx.data_ptr())
+        assert total == len(imgs) and skipped == 0
+        assert fidx.cpu().tolist() == frame_of
+        _, net = ctx.classifier_input(imgs, IMAGENET_MEAN, IMAGENET_STD, pad=pad)
+        np.testing.assert_array_equal(x.cpu().numpy(), net)
+    # chunked scoring through the classifier
+    sd = ref.calibrate_head(ref.random_state_dict(11), imgs)
+    path = tmp_path / "w.pt"
+    torch.save(sd, path)
+    clf = SegmentClassifier(str(path), batch_size=16)
+    s_dev, f_dev = clf.scores_from_device(ctx, inp, (FH, FW), segs, nseg, seg_cap)
+    s_host = clf.scores(imgs)
+    assert f_dev.cpu().tolist() == frame_of
+    np.testing.assert_allclose(s_dev.cpu().numpy(), s_host.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    exp_scores, _ = ref.classify(sd, imgs)
+    np.testing.assert_allclose(s_dev.cpu().numpy(), exp_scores, atol=2e-4, rtol=1e-4)
+    # a box at the frame edge is intersected with the frame; bad geometry is refused
+    inp_bad = _lib.Input(frames=dframes.data_ptr(), mem=_lib.MEM_HOST, channels=3, nwin=nwin, n=n, Hc=60, Wc=120,
+                         x0=40, y0=30, frame_stride=FH * FW * 3, row_stride=FW * 3)
+    with pytest.raises(_lib.SwkError):
+        ctx.segment_inputs(inp_bad, (FH, FW), segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN, IMAGENET_STD,
+                           x.data_ptr(), 4)
+    ctx.close()

@@ -37,7 +37,10 @@ def main():
     torch.cuda.synchronize()
     t_pre_w = time.perf_counter() - t0
     out = {}
-    for name, fn, xin in (("full", clf.model, x), ("cropped", clf.cropped, xw)):
+    which = (("full", clf.model, x), ("cropped", clf.cropped, xw))
+    if "--cropped-only" in sys.argv:
+        which = which[1:]
+    for name, fn, xin in which:
         for bs in (256, 1024, 2048):
             xb = xin[:bs]
             with torch.no_grad():
