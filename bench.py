@@ -28,8 +28,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per matrix element and IALM iteration of the streaming pass:
 #   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
-#   variant 3 (M state, the default):          X u8 + M f64 + U f32 read, M f64 + U f32 + S u8 written = 26; first = 14
-PASS_BYTES = {1: (33, 17), 2: (33, 17), 3: (26, 14)}
+#   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 + S u8 written = 22; first = 12
+PASS_BYTES = {1: (33, 17), 2: (33, 17), 3: (22, 12)}
 
 
 def parse():

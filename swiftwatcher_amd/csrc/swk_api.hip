@@ -260,7 +260,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_A, felems * 8, b.A);
     NEED(ctx, SL_Y, felems * 8, b.Y);
     if (variant == 3) {
-        b.U = (float *)b.Y;                  // f32 planes in the Y slot
+        b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
         NEED(ctx, SL_SALT, elems, b.Salt);
     }
     if (want_E) NEED(ctx, SL_E, felems * 8, b.E);

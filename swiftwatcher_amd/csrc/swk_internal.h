@@ -27,7 +27,7 @@ struct IalmBuffers {
     double *A, *Y;                 // [nwin][n][P]
     uint8_t *S;                    // [nwin][n][P]
     uint8_t *Salt;                 // v3: second sparse-image buffer (iteration parity), else null
-    float *U;                      // v3: Y/mu in f32 for the stopping norm, planes like A; b.A holds M
+    uint16_t *U;                   // v3: Y/mu as binary16 (x 1/128) for the stopping norm, planes like A; b.A holds M
     double *E;                     // optional [nwin][n][P]
     double *Bm;                    // [nwin][n][n]   I - W/mu
     double *Vprev;                 // [nwin][n][n]   eigenvectors of the previous solve (warm start)
