@@ -361,16 +361,22 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     });
     __syncthreads();
     // ---- run starts, in the id order of the numbering rule ----
+    // a foreground bit starts a run when the bit before it is clear or it sits in column 0: found a word at a time
     auto for_each_run_start = [&](auto fn) {
         for (int wi = tid; wi < rwords; wi += kFrameThreads) {
-            uint32_t m = fgr[wi];
-            while (m) {
-                const int bit = __ffs(m) - 1;
-                m &= m - 1;
-                const int b = (wi << 5) + bit;
-                const int r = b / W, c = b - r * W;
-                const bool start = c == 0 || !((fgr[(b - 1) >> 5] >> ((b - 1) & 31)) & 1u);
-                if (start) fn(b, r, c);
+            const uint32_t m = fgr[wi];
+            if (!m) continue;
+            const int w0 = wi << 5;
+            uint32_t col0 = 0;                                  // bits of this word that are the first pixel of a row
+            for (int b0 = ((w0 + W - 1) / W) * W; b0 < w0 + 32; b0 += W) col0 |= 1u << (b0 - w0);
+            const uint32_t prev = (m << 1) | (wi > 0 ? fgr[wi - 1] >> 31 : 0u);
+            uint32_t st = m & (~prev | col0);
+            while (st) {
+                const int bit = __ffs(st) - 1;
+                st &= st - 1;
+                const int b = w0 + bit;
+                const int r = b / W;
+                fn(b, r, b - r * W);
             }
         }
     };
@@ -496,6 +502,34 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
         }
         return label;
     };
+    if (by_runs) {
+        // sparse frame: clear the plane with full-width stores, then every run paints its own span
+        if (labels8) {
+            uint8_t *o = labels8 + (int64_t)f * P;
+            if ((P & 15) == 0 && (((uintptr_t)o) & 15) == 0) {
+                for (int i = tid; i < P / 16; i += kFrameThreads) ((uint4 *)o)[i] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (int i = tid; i < P; i += kFrameThreads) o[i] = 0;
+            }
+        }
+        if (labels32) {
+            int32_t *o = labels32 + (int64_t)f * P;
+            for (int i = tid; i < P; i += kFrameThreads) o[i] = 0;
+        }
+        __syncthreads();
+        for (int run = tid; run < nruns; run += kFrameThreads) {
+            const int r = run_rc[run] >> 16, cs = run_rc[run] & 0xffff, ce = run_ce[run];
+            const int label = rlab[run];
+            if (labels8) {
+                uint8_t *o = labels8 + (int64_t)f * P + r * W;
+                for (int c = cs; c <= ce; ++c) o[c] = (uint8_t)label;
+            }
+            if (labels32) {
+                int32_t *o = labels32 + (int64_t)f * P + r * W;
+                for (int c = cs; c <= ce; ++c) o[c] = label;
+            }
+        }
+    } else {
     for_each_word<VEC>(img, nwords, [&](int i, uint32_t v) {
         uint32_t packed = 0;
         int lab[VEC];
@@ -516,6 +550,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
             for (int k = 0; k < VEC; ++k) o[k] = lab[k];
         }
     });
+    }
     if (!PROPS) return;
     __syncthreads();
     // ---- ascending-label segment list ----
