@@ -225,28 +225,51 @@ void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint
 // at once for those and their outputs stay at the zero the buffers were cleared to.
 // ---------------------------------------------------------------------------------
 
+// marks every tile whose source window (tile + halo) contains pixel range [p, p + cnt) of the frame, cnt <= 4
+__device__ __forceinline__ void mark_tiles(uint8_t *fl, int p, int cnt, int H, int W, int ntx)
+{
+    const int r = p / W, c = p - r * W;          // a short range may wrap to the next row: widen the column range
+    int c_lo = c, c_hi = c + cnt - 1, r_hi = r;
+    if (c_hi >= W) { c_lo = 0; c_hi = W - 1; r_hi = r + 1 < H ? r + 1 : H - 1; }
+    const int tr0 = (r - kHalo > 0 ? r - kHalo : 0) / kTH, tr1 = (r_hi + kHalo < H - 1 ? r_hi + kHalo : H - 1) / kTH;
+    const int tc0 = (c_lo - kHalo > 0 ? c_lo - kHalo : 0) / kTW, tc1 = (c_hi + kHalo < W - 1 ? c_hi + kHalo : W - 1) / kTW;
+    for (int tr = tr0; tr <= tr1; ++tr)
+        for (int tc = tc0; tc <= tc1; ++tc) fl[tr * ntx + tc] = 1;
+}
+
+// VEC = 16: four uint4 loads in flight per thread; VEC = 4 / 1: one word per thread (unaligned or odd-sized planes)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tile_flags(const uint8_t *__restrict__ src, int H, int W, int ntx, int nty,
                                                     uint8_t *__restrict__ flags)
 {
     const int f = blockIdx.y;
     const int P = H * W;
+    const uint8_t *img = src + (int64_t)f * P;
+    uint8_t *fl = flags + (int64_t)f * ntx * nty;
+    if (VEC == 16) {
+        const int nv = P / 16;
+        const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < nv ? ((const uint4 *)img)[i0 + k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(v[k].x | v[k].y | v[k].z | v[k].w)) continue;
+            const int p = (i0 + k) * 16;
+            if (v[k].x) mark_tiles(fl, p, 4, H, W, ntx);
+            if (v[k].y) mark_tiles(fl, p + 4, 4, H, W, ntx);
+            if (v[k].z) mark_tiles(fl, p + 8, 4, H, W, ntx);
+            if (v[k].w) mark_tiles(fl, p + 12, 4, H, W, ntx);
+        }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P / VEC) return;
-    const uint8_t *img = src + (int64_t)f * P;
     uint32_t v;
     if (VEC == 4) v = ((const uint32_t *)img)[i];
     else v = img[i];
     if (!v) return;
-    const int p = i * VEC;
-    const int r = p / W, c = p - r * W;          // a 4-pixel word may wrap to the next row: widen the column range
-    int c_lo = c, c_hi = c + VEC - 1, r_hi = r;
-    if (c_hi >= W) { c_lo = 0; c_hi = W - 1; r_hi = r + 1 < H ? r + 1 : H - 1; }
-    const int tr0 = (r - kHalo > 0 ? r - kHalo : 0) / kTH, tr1 = (r_hi + kHalo < H - 1 ? r_hi + kHalo : H - 1) / kTH;
-    const int tc0 = (c_lo - kHalo > 0 ? c_lo - kHalo : 0) / kTW, tc1 = (c_hi + kHalo < W - 1 ? c_hi + kHalo : W - 1) / kTW;
-    uint8_t *fl = flags + (int64_t)f * ntx * nty;
-    for (int tr = tr0; tr <= tr1; ++tr)
-        for (int tc = tc0; tc <= tc1; ++tc) fl[tr * ntx + tc] = 1;
+    mark_tiles(fl, i * VEC, VEC, H, W, ntx);
 }
 
 // ---------------------------------------------------------------------------------
@@ -255,9 +278,10 @@ __global__ __launch_bounds__(256) void k_tile_flags(const uint8_t *__restrict__ 
 // 3 px beyond that: a 42-row source tile in LDS (80 columns: the window starts 8 px left of the tile so interior
 // tiles load it as aligned dwords).  The stage is instruction-bound, so the work is made as sparse as the data:
 //   * empty tiles never start (tile flags), outputs are pre-cleared;
-//   * a separable 7x7 OR finds the ring cells whose neighbourhood holds any nonzero pixel; only those are
-//     compacted into a list and run the 29-tap loop (a cell with an all-zero neighbourhood filters to 0);
-//   * erosion of a zero pixel is zero without looking further; an all-zero eroded tile ends the block.
+//   * the nonzero pixels of the source tile are kept as one 80-bit mask per row; shifts and ORs of those masks give
+//     the ring cells whose 7x7 neighbourhood holds any nonzero pixel, and only those cells -- listed from the set
+//     bits -- run the 29-tap loop (a cell with an all-zero neighbourhood filters to 0);
+//   * erosion runs over the same list (a zero pixel erodes to zero); an all-zero eroded tile ends the block.
 // ---------------------------------------------------------------------------------
 constexpr int kR = 3;                    // bilateral radius of the fused kernel
 constexpr int kSH = kTH + 2 * kHalo;     // 42 source rows
@@ -276,9 +300,11 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
     // empty tile (source window all zero): every stage outputs zero, which the buffers already hold
     if (flags && !flags[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
     __shared__ __attribute__((aligned(16))) uint8_t s_src[kSH * kSP];
-    __shared__ uint8_t s_or[kSH * kBW];            // horizontal 7-wide OR of the source, per ring column
-    __shared__ uint8_t s_thr[kBH * kBW];
-    __shared__ uint8_t s_er[kEH * kEW];
+    __shared__ uint32_t s_nz[kSH * 3];             // per source row: 80-bit mask of its nonzero pixels
+    __shared__ unsigned long long s_hlo[kSH];      // per source row: bit lc = some nonzero among source columns lc+3 .. lc+9
+    __shared__ uint32_t s_hhi[kSH];
+    __shared__ __attribute__((aligned(4))) uint8_t s_thr[kBH * kBW];
+    __shared__ __attribute__((aligned(4))) uint8_t s_er[kEH * kEW];
     __shared__ uint16_t s_list[kBH * kBW];
     __shared__ float s_cw[256];
     __shared__ float s_sw[32];
@@ -293,48 +319,75 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
         s_sw[tid] = space_w[tid];
         s_ofs[tid] = (int)tdr[tid] * kSP + (int)tdc[tid];
     }
-    for (int i = tid; i < kBH * kBW; i += 256) s_thr[i] = 0;
-    // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71 ----
+    for (int i = tid; i < kBH * kBW / 4; i += 256) ((uint32_t *)s_thr)[i] = 0u;
+    for (int i = tid; i < kEH * kEW / 4; i += 256) ((uint32_t *)s_er)[i] = 0u;
+    if (tid < kSH * 3) s_nz[tid] = 0u;
+    __syncthreads();
+    // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71; its nonzero pixels also go into row bit masks ----
     const bool interior = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W &&
                           (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
     if (interior) {
         for (int i = tid; i < kSH * (kSP / 4); i += 256) {
             const int sr = i / (kSP / 4), q = i - sr * (kSP / 4);
-            ((uint32_t *)s_src)[i] = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
+            const uint32_t v = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
+            ((uint32_t *)s_src)[i] = v;
+            if (v) {
+                const uint32_t nib = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) |
+                                     ((v & 0xff000000u) ? 8u : 0u);
+                atomicOr(&s_nz[sr * 3 + (q >> 3)], nib << (4 * (q & 7)));
+            }
         }
     } else {
         for (int i = tid; i < kSH * kSP; i += 256) {
             const int sr = i / kSP, sc = i - sr * kSP;
             // taps of in-image pixels reach outside the image by up to kR and use BORDER_REFLECT_101 there, so every
             // cell holds img[reflect101(coordinate)]; cells far outside the image are never consumed
-            s_src[i] = img[reflect101(r0 - kHalo + sr, H) * W + reflect101(c0 - kSX + sc, W)];
+            const uint8_t v = img[reflect101(r0 - kHalo + sr, H) * W + reflect101(c0 - kSX + sc, W)];
+            s_src[i] = v;
+            if (v) atomicOr(&s_nz[sr * 3 + (sc >> 5)], 1u << (sc & 31));
         }
     }
     __syncthreads();
-    // ---- horizontal OR over the 7 source columns under each ring column ----
-    for (int i = tid; i < kSH * kBW; i += 256) {
-        const int sr = i / kBW, lc = i - sr * kBW;
-        const uint8_t *p = &s_src[sr * kSP + lc + (kSX - kHalo)];       // ring column lc = source columns lc+3 .. lc+9
-        s_or[i] = p[0] | p[1] | p[2] | p[3] | p[4] | p[5] | p[6];
+    // ---- horizontal 7-wide OR, one source row per thread, as shifts of the row mask ----
+    if (tid < kSH) {
+        const unsigned long long lo = (unsigned long long)s_nz[tid * 3] | ((unsigned long long)s_nz[tid * 3 + 1] << 32);
+        const unsigned long long hi = s_nz[tid * 3 + 2];
+        unsigned long long alo = 0, ahi = 0;
+#pragma unroll
+        for (int d = kSX - kHalo; d <= kSX - kHalo + 2 * kR; ++d) {       // ring column lc = source columns lc+3 .. lc+9
+            alo |= (lo >> d) | (hi << (64 - d));
+            ahi |= hi >> d;
+        }
+        s_hlo[tid] = alo;
+        s_hhi[tid] = (uint32_t)ahi;
     }
     __syncthreads();
-    // ---- live ring cells: in the image and with a nonzero pixel somewhere in their 7x7 neighbourhood ----
-    for (int base = 0; base < kBH * kBW; base += 256) {
-        const int i = base + tid;
-        bool live = false;
-        if (i < kBH * kBW) {
-            const int lr = i / kBW, lc = i - lr * kBW;
-            const int r = r0 - 2 + lr, c = c0 - 2 + lc;
-            if (r >= 0 && r < H && c >= 0 && c < W) {
-                const uint8_t *p = &s_or[lr * kBW + lc];
-                live = (p[0] | p[kBW] | p[2 * kBW] | p[3 * kBW] | p[4 * kBW] | p[5 * kBW] | p[6 * kBW]) != 0;
-            }
+    // ---- live ring cells: in the image and with a nonzero pixel somewhere in their 7x7 neighbourhood.
+    //      One ring row per thread: vertical OR of seven row masks, then the set bits go to the list. ----
+    if (tid < kBH) {
+        const int lr = tid;
+        const int r = r0 - 2 + lr;
+        unsigned long long vlo = 0;
+        uint32_t vhi = 0;
+        if (r >= 0 && r < H) {
+#pragma unroll
+            for (int j = 0; j <= 2 * kR; ++j) { vlo |= s_hlo[lr + j]; vhi |= s_hhi[lr + j]; }
+            // columns inside the image: lc in [max(0, 2 - c0), min(kBW - 1, W + 1 - c0)]
+            const int lc_lo = 2 - c0 > 0 ? 2 - c0 : 0;
+            const int lc_hi = W + 1 - c0 < kBW - 1 ? W + 1 - c0 : kBW - 1;
+            unsigned long long mlo = ~0ull;
+            uint32_t mhi = (1u << (kBW - 64)) - 1u;
+            if (lc_lo > 0) mlo &= ~((1ull << lc_lo) - 1ull);
+            if (lc_hi < 63) { mlo &= (1ull << (lc_hi + 1)) - 1ull; mhi = 0u; }
+            else if (lc_hi < kBW - 1) mhi &= (1u << (lc_hi - 63)) - 1u;
+            vlo &= mlo; vhi &= mhi;
         }
-        const unsigned long long m = __ballot(live);
-        int wbase = 0;
-        if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_count, __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (live) s_list[wbase + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+        const int cnt = __popcll(vlo) + __popc(vhi);
+        if (cnt) {
+            int pos = atomicAdd(&s_count, cnt);
+            while (vlo) { const int bit = __ffsll((long long)vlo) - 1; vlo &= vlo - 1; s_list[pos++] = (uint16_t)(lr * kBW + bit); }
+            while (vhi) { const int bit = __ffs(vhi) - 1; vhi &= vhi - 1; s_list[pos++] = (uint16_t)(lr * kBW + 64 + bit); }
+        }
     }
     __syncthreads();
     // ---- bilateral + threshold on the compacted list ----
@@ -362,20 +415,23 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
         s_thr[i] = outv;
     }
     __syncthreads();
-    // ---- erosion (window coordinates clamp to the IMAGE: scipy 'reflect' == edge replicate at radius 1) ----
+    // ---- erosion (window coordinates clamp to the IMAGE: scipy 'reflect' == edge replicate at radius 1).
+    //      Only a live cell can have survived the threshold, and the minimum over a window is 0 as soon as its
+    //      centre is: the pass runs over the list (cells of the eroded ring outside the image are never read). ----
     int er_any = 0;
-    for (int i = tid; i < kEH * kEW; i += 256) {
-        const int er = i / kEW, ec = i - er * kEW;
-        const int r = clampi(r0 - 1 + er, H), c = clampi(c0 - 1 + ec, W);
-        int acc = s_thr[(r - r0 + 2) * kBW + (c - c0 + 2)];
-        if (acc) {                                   // min over the window is 0 as soon as the centre is 0
-            for (int dr = -1; dr <= 1; ++dr)
-                for (int dc = -1; dc <= 1; ++dc) {
-                    const int v = s_thr[(clampi(r + dr, H) - r0 + 2) * kBW + (clampi(c + dc, W) - c0 + 2)];
-                    acc = v < acc ? v : acc;
-                }
-        }
-        s_er[i] = (uint8_t)acc;
+    for (int j = tid; j < nlive; j += 256) {
+        const int i = s_list[j];
+        int acc = s_thr[i];
+        if (!acc) continue;
+        const int lr = i / kBW, lc = i - lr * kBW;
+        if (lr < 1 || lr > kEH || lc < 1 || lc > kEW) continue;          // outermost ring layer: not an erosion cell
+        const int r = r0 - 2 + lr, c = c0 - 2 + lc;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int v = s_thr[(clampi(r + dr, H) - r0 + 2) * kBW + (clampi(c + dc, W) - c0 + 2)];
+                acc = v < acc ? v : acc;
+            }
+        s_er[(lr - 1) * kEW + (lc - 1)] = (uint8_t)acc;
         er_any |= acc;
     }
     if (er_any) s_er_any = 1;
@@ -410,9 +466,13 @@ void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W,
         (void)hipMemsetAsync(flags, 0, (size_t)F * ntx * nty, s);
         const int P = H * W;
         const bool vec4 = (P % 4 == 0) && (((uintptr_t)src & 3) == 0);
+        const bool vec16 = (P % 16 == 0) && (((uintptr_t)src & 15) == 0);
         for (int f0 = 0; f0 < F; f0 += 32768) {
             const int fc = F - f0 < 32768 ? F - f0 : 32768;
-            if (vec4)
+            if (vec16)
+                hipLaunchKernelGGL(k_tile_flags<16>, dim3((P / 64 + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
+                                   flags + (size_t)f0 * ntx * nty);
+            else if (vec4)
                 hipLaunchKernelGGL(k_tile_flags<4>, dim3((P / 4 + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
                                    flags + (size_t)f0 * ntx * nty);
             else
