@@ -28,8 +28,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per matrix element and IALM iteration of the streaming pass:
 #   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
-#   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 + S u8 written = 22; first = 12
-PASS_BYTES = {1: (33, 17), 2: (33, 17), 3: (22, 12)}
+#   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 written = 21; first = 11;
+#                                              the sparse u8 image is needed once per window (+1 B per element, booked
+#                                              once: the passes far from convergence do not store it)
+PASS_BYTES = {1: (33, 17, 0), 2: (33, 17, 0), 3: (21, 11, 1)}
 
 
 def parse():
@@ -168,8 +170,8 @@ def main():
         # exact algorithmic bytes streamed by the full passes of ONE step (same every step: same data)
         elems = n * P
         variant = args.variant if args.variant else 3
-        BYTES_STEADY, BYTES_FIRST = PASS_BYTES[variant]
-        step_bytes = int(sum(BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems
+        BYTES_STEADY, BYTES_FIRST, BYTES_ONCE = PASS_BYTES[variant]
+        step_bytes = int(sum(BYTES_ONCE + BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems
         total_bytes = step_bytes * args.steps
         achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
         traffic = None

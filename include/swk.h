@@ -228,6 +228,12 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
  * element and iteration; produces the sparse u8 image and the iteration count, not A / E).
  * For A/B measurements only. */
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
+/* M-state pass only: the per-iteration stores of the sparse u8 image start once ||Z||_F < factor * tol * ||X||_F
+ * (default 16; <= 0 = every pass).  A window that stops although the pass before its last iteration skipped the
+ * stores makes the library run the batch again without the speculation, so results never depend on the factor;
+ * swk_prof_redo_batches counts those reruns. */
+int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor);
+int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
 /* Window groups whose eigen-solves overlap the other groups' streaming passes:
  * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */
 int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);

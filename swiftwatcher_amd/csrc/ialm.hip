@@ -75,6 +75,7 @@ __global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda)
     s.cur = s.nxt;
     s.iter = 0;
     s.sweeps = 0;
+    s.ws = 1; s.ws_prev = 1; s.redo = 0;
     // an all-zero window has nothing to decompose (the reference would divide by zero)
     s.done = s.sumsq == 0 ? 1 : 0;
     if (!s.done) atomicAdd(active, 1);

@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
 // recomputed in f64 from M_k).
 // The sparse image has to come from an exact E: pass k computes E_{k+1} exactly (it builds M_{k+1} from it) and
 // writes its u8 form to S[k & 1]; when iteration K turns out to be the last, E_K is what pass K-1 left in
-// S[(K-1) & 1] (k_select_sparse moves it to S[0] for odd K-1).  A and E in f64 are not produced: callers that ask
+// S[(K-1) & 1] (k_select_sparse moves it to S[0] for odd K-1).  Those stores are 16-byte row pieces and cost 2.5x
+// their share of the bytes, so k_ialm_small switches them off while ||Z|| is still far above the threshold
+// (IalmWin::ws) and flags the window for a rerun should the iteration stop anyway (IalmWin::redo).  A and E in f64 are not produced: callers that ask
 // for them run v2.
 // ---------------------------------------------------------------------------------
 // U travels as binary16 of U / 128: |U| <= 1/mu_1 < ||X||_F / 1.8 <= 2.3e6 for every admissible window, so
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const int w = blockIdx.y;
     const IalmWin &st = b.win[w];
     if (st.done) return;
+    const bool ws = st.ws != 0;                  // sparse-image stores on for this pass (k_ialm_small decides)
     const int n = b.n, P = b.P;
     const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
         const unsigned vo8 = pvalid ? ((unsigned)fr0 * ps32 + p) * 8u : kOob;     // f64 planes
         const unsigned vo2 = pvalid ? ((unsigned)fr0 * ps32 + p) * 2u : kOob;     // binary16 planes
         const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
+        const unsigned vo1s = ws ? vo1 : kOob;
         int xi[NK];
         double mv[NK];
         float uf[NK];
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                         buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
                         buf_st16h((float)u, rU, fvalid ? vo2 : kOob, (unsigned)(4 * t) * ps32 * 2u);
                     }
-                    buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
+                    buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1s : kOob, (unsigned)(4 * t) * P32);
                 }
             }
         }

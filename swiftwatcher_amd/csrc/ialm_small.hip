@@ -49,9 +49,16 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         }
         const double ratio = sqrt(red[0]) / st.dnorm;            // :297
         if (ratio < tol || k >= maxiter) {
-            if (tid == 0) { st.iter = k; st.done = 1; atomicSub(b.active, 1); }
+            // the answer's sparse image is the one pass k-1 wrote (ialm_mfma.hip, M-state pass): if that pass ran
+            // with its stores switched off, the speculation below failed and the host runs the batch again
+            if (tid == 0) { st.iter = k; st.done = 1; if (!st.ws_prev) st.redo = 1; atomicSub(b.active, 1); }
             return false;
         }
+        // far from the stopping threshold the next iteration cannot be the last but one: its pass skips the
+        // sparse-image stores (a u8 plane written in 16-byte row pieces costs 2.5x its share of the bytes)
+        if (tid == 0) { st.ws_prev = st.ws; st.ws = (b.spec <= 0.0 || ratio < b.spec * tol) ? 1 : 0; }
+    } else if (tid == 0) {
+        st.ws_prev = st.ws; st.ws = 1;
     }
     cur = st.nxt;
     IalmScal nxt;

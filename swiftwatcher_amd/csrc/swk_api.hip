@@ -44,6 +44,8 @@ struct swk_ctx {
     int64_t prof_n[SWK_K_COUNT] = {0};
     int64_t window_iters = 0;
     int ialm_variant = 0;
+    double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
+    int64_t redo_batches = 0;
     int ialm_groups = 0;                 // 0 = auto
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
     int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
@@ -232,7 +234,8 @@ int ensure_ccl(swk_ctx *ctx, int F, int H, int W, CclBuffers *b)
 
 // ---- IALM driver ----------------------------------------------------------------------
 int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmbda, double tol, int maxiter,
-             bool want_A, bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/)
+             bool want_A, bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/,
+             bool speculate = true)
 {
     if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
     IalmBuffers b{};
@@ -261,6 +264,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_Y, felems * 8, b.Y);
     if (variant == 3) {
         b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
+        b.spec = speculate ? ctx->sparse_spec : 0.0;
         NEED(ctx, SL_SALT, elems, b.Salt);
     }
     if (want_E) NEED(ctx, SL_E, felems * 8, b.E);
@@ -365,6 +369,18 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // everything after the IALM runs on the main stream: join the side streams
     for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
     if (variant == 3) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
+    if (variant == 3 && b.spec > 0.0) {
+        // did any window stop right after a pass that had its sparse-image stores switched off?
+        std::vector<IalmWin> hw(nwin);
+        HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        bool redo = false;
+        for (int w = 0; w < nwin; ++w) redo = redo || hw[w].redo != 0;
+        if (redo) {
+            ctx->redo_batches += 1;
+            return run_ialm(ctx, dX, nwin, n, P, lmbda, tol, maxiter, want_A, want_E, dS, h_iters, d_iters, false);
+        }
+    }
     ctx->last_win = b.win;
     ctx->last_nwin = nwin;
     (void)h_iters; (void)d_iters;
@@ -508,6 +524,19 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
     if (!ctx || variant < 0 || variant > 3) return SWK_ERR_ARG;
     ctx->ialm_variant = variant;
+    return SWK_OK;
+}
+
+int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    ctx->sparse_spec = factor;
+    return SWK_OK;
+}
+int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)
+{
+    if (!ctx || !batches) return SWK_ERR_ARG;
+    *batches = ctx->redo_batches;
     return SWK_OK;
 }
 

@@ -20,6 +20,8 @@ struct IalmWin {
     int iter;                      // iterations completed
     int done;
     int sweeps;                    // Jacobi sweeps used by the last eigen solve (diagnostic)
+    int ws, ws_prev;               // M-state pass: did / does the pass of this (the previous) iteration write the sparse image
+    int redo;                      // the last iteration's sparse image was not written: the window has to be run again
 };
 
 struct IalmBuffers {
@@ -36,6 +38,7 @@ struct IalmBuffers {
     IalmWin *win;                  // [nwin]
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;
+    double spec;                   // M-state pass: sparse image written only once ||Z|| < spec * tol * ||X|| (<= 0: always)
     int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
     int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows

@@ -202,6 +202,33 @@ def test_pass_kernels_agree_at_full_size():
     assert a["segs"].tobytes() == b["segs"].tobytes()
 
 
+def test_sparse_store_speculation_never_changes_results(orc):
+    """The M-state pass skips the per-iteration stores of the sparse image while ||Z|| is far above the stopping
+    threshold.  Whatever the factor -- stores always on (0), the default (16 x tol), or a factor so small that the
+    stores are still off when the iteration stops, which forces the rerun path -- the outputs are the oracle's."""
+    from swiftwatcher_amd import _lib, synthetic
+    roi = np.concatenate([synthetic.roi_window(40 + w, 21, 64, 96, birds=3 + w, bird_len=(8, 14), bird_wid=(3, 6))
+                          for w in range(3)])
+    refs = [orc.window(np.ascontiguousarray(roi[w * 21:(w + 1) * 21])) for w in range(3)]
+    for factor, want_redo in ((0.0, False), (16.0, False), (1e-9, True)):
+        c = _lib.Context(0)
+        c.set_sparse_speculation(factor)
+        res = c.batch_run(roi, 3, 21, stages=("rpca", "labels"))
+        assert (c.redo_batches > 0) == want_redo, (factor, c.redo_batches)
+        for w in range(3):
+            sl = slice(w * 21, (w + 1) * 21)
+            np.testing.assert_array_equal(res["rpca"][sl], refs[w]["rpca"], err_msg="factor %g window %d" % (factor, w))
+            np.testing.assert_array_equal(res["labels"][sl], refs[w]["labels"])
+        # an iteration cap that stops the loop early must also go through the rerun and still be exact
+        p = _lib.default_params()
+        p.maxiter = 4
+        res = c.batch_run(roi[:21], 1, 21, params=p, stages=("rpca",))
+        ref = orc.window(np.ascontiguousarray(roi[:21]), maxiter=4)
+        assert int(res["iters"][0]) == 4
+        np.testing.assert_array_equal(res["rpca"], ref["rpca"])
+        c.close()
+
+
 def test_ialm_vs_oracle_and_null_frames(ctx, orc):
     from swiftwatcher_amd import synthetic
     roi = synthetic.roi_window(11, 21, 64, 96, birds=4, bird_len=(8, 14), bird_wid=(3, 6), null_frames=4)
