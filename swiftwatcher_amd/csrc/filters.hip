@@ -234,7 +234,8 @@ __device__ __forceinline__ void mark_tiles(uint8_t *fl, int p, int cnt, int H, i
     const int tr0 = (r - kHalo > 0 ? r - kHalo : 0) / kTH, tr1 = (r_hi + kHalo < H - 1 ? r_hi + kHalo : H - 1) / kTH;
     const int tc0 = (c_lo - kHalo > 0 ? c_lo - kHalo : 0) / kTW, tc1 = (c_hi + kHalo < W - 1 ? c_hi + kHalo : W - 1) / kTW;
     for (int tr = tr0; tr <= tr1; ++tr)
-        for (int tc = tc0; tc <= tc1; ++tc) fl[tr * ntx + tc] = 1;
+        for (int tc = tc0; tc <= tc1; ++tc)
+            if (!fl[tr * ntx + tc]) fl[tr * ntx + tc] = 1;       // mostly a cached read: hundreds of words mark the same tile
 }
 
 // VEC = 16: four uint4 loads in flight per thread; VEC = 4 / 1: one word per thread (unaligned or odd-sized planes)

@@ -1,6 +1,6 @@
 // Memory-shape probe for the M-state IALM pass (diagnostic, not part of the library): moves exactly the pass's
-// bytes (X u8 + M f64 + U f32 read, M f64 + U f32 + S u8 written in place) with no arithmetic, in two shapes:
-//   shape 0: as k_ialm_pass_v3 -- per 16-pixel tile, every plane as 16-pixel row segments (X/S: 16 B, U: 64 B, M: 128 B)
+// bytes (X u8 + M f64 + U f16 read, M f64 + U f16 + S u8 written in place) with no arithmetic, in two shapes:
+//   shape 0: as k_ialm_pass_v3 -- per 16-pixel tile, every plane as 16-pixel row segments (X/S: 16 B, U: 32 B, M: 128 B)
 //   shape 1: X and S as one dword per lane over a 64-pixel super-tile (64-B row segments), U and M per tile as before
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/pass_probe tools/pass_probe.hip
 #include <hip/hip_runtime.h>
@@ -9,7 +9,7 @@
 
 template <int SHAPE>
 __global__ __launch_bounds__(256, 2) void k_probe(const uint8_t *__restrict__ X, uint8_t *__restrict__ S, double *__restrict__ M,
-                                                   float *__restrict__ U, int P, int ntiles)
+                                                   unsigned short *__restrict__ U, int P, int ntiles)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, fr0 = lane >> 4;
@@ -22,13 +22,13 @@ __global__ __launch_bounds__(256, 2) void k_probe(const uint8_t *__restrict__ X,
                 const int tile = lg * 8 + wave * 2 + h;
                 if (tile >= ntiles) continue;
                 const size_t o = (size_t)fr0 * P + tile * 16 + pl;
-                int x[16]; double m[16]; float u[16];
+                int x[16]; double m[16]; unsigned short u[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) { x[t] = X[o + (size_t)4 * t * P]; m[t] = M[o + (size_t)4 * t * P]; u[t] = U[o + (size_t)4 * t * P]; }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     M[o + (size_t)4 * t * P] = m[t] + (double)u[t];
-                    U[o + (size_t)4 * t * P] = u[t] + (float)x[t];
+                    U[o + (size_t)4 * t * P] = (unsigned short)(u[t] + x[t]);
                     S[o + (size_t)4 * t * P] = (uint8_t)(x[t] + 1);
                 }
             }
@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256, 2) void k_probe(const uint8_t *__restrict__ X,
                 const int tile = st * 4 + q;
                 if (tile >= ntiles) break;
                 const size_t o = (size_t)fr0 * P + tile * 16 + pl;
-                double m[16]; float u[16];
+                double m[16]; unsigned short u[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) { m[t] = M[o + (size_t)4 * t * P]; u[t] = U[o + (size_t)4 * t * P]; }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int x = (xd[t] >> (8 * q)) & 255;
                     M[o + (size_t)4 * t * P] = m[t] + (double)u[t];
-                    U[o + (size_t)4 * t * P] = u[t] + (float)x;
+                    U[o + (size_t)4 * t * P] = (unsigned short)(u[t] + x);
                     sd[t] |= (uint32_t)((x + 1) & 255) << (8 * q);
                 }
             }
@@ -65,10 +65,10 @@ int main()
 {
     const int W = 128, P = 89888;           // P % 64 == 32: the last super-tile is half full (bytes past P land in the next plane: harmless here)
     const size_t elems = (size_t)W * 64 * P;
-    uint8_t *X, *S; double *M; float *U;
+    uint8_t *X, *S; double *M; unsigned short *U;
     if (hipMalloc(&X, elems + 256) != hipSuccess || hipMalloc(&S, elems + 256) != hipSuccess || hipMalloc(&M, elems * 8) != hipSuccess ||
-        hipMalloc(&U, elems * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    (void)hipMemset(X, 1, elems); (void)hipMemset(S, 0, elems); (void)hipMemset(M, 0, elems * 8); (void)hipMemset(U, 0, elems * 4);
+        hipMalloc(&U, elems * 2) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMemset(X, 1, elems); (void)hipMemset(S, 0, elems); (void)hipMemset(M, 0, elems * 8); (void)hipMemset(U, 0, elems * 2);
     const int ntiles = (P + 15) / 16;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int shape = 0; shape < 2; ++shape)
@@ -78,7 +78,7 @@ int main()
             else hipLaunchKernelGGL(k_probe<1>, dim3(12, W), dim3(256), 0, 0, X, S, M, U, P, ntiles);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-            if (rep) printf("shape %d  %.3f ms  %.1f GB/s algorithmic (26 B/element)\n", shape, ms, (double)elems * 26 / ms * 1e-6);
+            if (rep) printf("shape %d  %.3f ms  %.1f GB/s algorithmic (22 B/element)\n", shape, ms, (double)elems * 22 / ms * 1e-6);
         }
     return 0;
 }

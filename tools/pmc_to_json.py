@@ -4,7 +4,7 @@ HBM traffic of one launch of the steady-state IALM pass = FETCH_SIZE x calibrati
 MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies a 128-B request as 64 B; "other access widths are uncalibrated:
 calibrate on a known byte count in your own access pattern".  The pass mixes 128-B (f64), 64-B (f32) and 16-B (u8)
 row segments, so the read factor is taken from tools/pass_probe (shape 0: exactly the pass's loads and stores, no
-arithmetic, known 13 B read per element): factor = 13 / counted.  WRITE_SIZE is used as counted (it reports the
+arithmetic, known 11 B read per element): factor = 11 / counted.  WRITE_SIZE is used as counted (it reports the
 partial-line writes of the u8 plane at their burst size: that is traffic)."""
 import json, re, sys
 
@@ -15,7 +15,7 @@ c = summ[key]
 probe = open(meas + "/pass_probe.txt").read()
 counted = float(re.search(r"k_probe<0>.*FETCH_SIZE counted B/elt ([0-9.]+)", probe).group(1))
 counted_w = float(re.search(r"k_probe<0>.*WRITE_SIZE counted B/elt ([0-9.]+)", probe).group(1))
-factor = 13.0 / counted
+factor = 11.0 / counted
 W, n, P = 128, 64, 89888
 elems = W * n * P
 # the per-dispatch means include the lag launch that finds every window finished (0 bytes): 15 dispatches, 14 live
@@ -25,14 +25,15 @@ read_b, write_b = fetch_kb * 1024 * factor, write_kb * 1024
 out = {
     "kernel": "k_ialm_pass_v3<4,2,true>", "variant": 3, "windows_per_dispatch": W, "n": n, "P": P,
     "FETCH_SIZE_KB_per_live_dispatch": fetch_kb, "WRITE_SIZE_KB_per_live_dispatch": write_kb,
-    "fetch_calibration": {"probe": "tools/pass_probe shape 0 (same loads/stores, known 13 B read + 13 B written per element)",
+    "fetch_calibration": {"probe": "tools/pass_probe shape 0 (same loads/stores, known 11 B read + 11 B written per element)",
                           "counted_read_B_per_element": counted, "factor": factor,
                           "counted_write_B_per_element": counted_w},
     "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "hbm_bytes_per_window_pass": (read_b + write_b) / W,
-    "algorithmic_bytes_per_window_pass": 26 * n * P,
-    "traffic_over_algorithmic": (read_b + write_b) / (26.0 * elems),
+    "algorithmic_bytes_per_window_pass": 21 * n * P,
+    "note": "21 B = X u8 + M f64 + U f16 read, M f64 + U f16 written; the measured traffic also contains the sparse-image stores (1 B) of the passes near convergence",
+    "traffic_over_algorithmic": (read_b + write_b) / (21.0 * elems),
     "counters_mean_per_dispatch": c,
 }
 json.dump(out, open(sys.argv[2], "w"), indent=1)
