@@ -224,7 +224,7 @@ int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *la
 /* Total IALM pass launches x windows still active, i.e. window-iterations streamed. */
 int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
 /* Select the IALM pass kernel: 0 = auto (3, or 2 when A / E are requested), 1 = LDS/VALU kernel,
- * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (26 instead of 34 B per
+ * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per
  * element and iteration; produces the sparse u8 image and the iteration count, not A / E).
  * For A/B measurements only. */
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);

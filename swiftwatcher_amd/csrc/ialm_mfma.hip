@@ -18,7 +18,7 @@
 //   (G is symmetric); accumulators stay in registers over the wave's whole tile loop.
 //
 // No barrier inside the loop: waves only share the read-only B matrix.
-// Roofline: HBM.  v2: 33 B/element/iteration (+1 for the sparse image), v3 below: 26 B; against 4n^2 flop/pixel -> 7.8 flop/B at n = 64, under the
+// Roofline: HBM.  v2: 33 B/element/iteration (+1 for the sparse image), v3 below: 21 B (+1 when it stores the sparse image); against 4n^2 flop/pixel -> 7.8 flop/B at n = 64, under the
 // f64 ridge of ~9.8 flop/B (78.6 TF / 8 TB/s); at n = 21 it is 2.5 flop/B.
 #include "swk_internal.h"
 

@@ -240,7 +240,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
-    // auto: the M-state pass (v3, 26 B/element) unless the caller wants the f64 low-rank / sparse matrices,
+    // auto: the M-state pass (v3, 21 B/element) unless the caller wants the f64 low-rank / sparse matrices,
     // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = ctx->ialm_variant;
     if (variant == 0) variant = 3;

@@ -184,7 +184,7 @@ def test_sparse_image_golden_without_float_outputs(ctx, golden_dir, name):
 
 
 def test_pass_kernels_agree_at_full_size():
-    """424x212 x 64 frames, four windows with different content: the M-state pass (26 B/element) and the
+    """424x212 x 64 frames, four windows with different content: the M-state pass (21 B/element) and the
     A/Y-state pass (34 B/element) give the same iteration counts, sparse images, labels and regions."""
     from swiftwatcher_amd import _lib, synthetic
     roi = np.concatenate([synthetic.roi_window(70 + w, 64, 212, 424, birds=4 + 5 * w) for w in range(4)])
