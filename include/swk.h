@@ -200,6 +200,16 @@ int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, i
                            const float mean[3], const float std_[3], int32_t pad, int32_t first, int32_t net_cap,
                            float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped);
 
+/* Glue of the receptive-field cropped classifier, launched on the CALLER's HIP stream (PyTorch's current stream;
+ * no context): channels-last dense float32 tensors, (n, c, h, w) = memory [n][h][w][c], c multiple of 4.
+ * bias_relu_place: dst[n][off_y+y][off_x+x][c_off+ch] = max(src[n][crop_y+y][crop_x+x][ch] + bias[ch], 0), the three
+ * passes PyTorch makes between two convolutions (bias add, ReLU, copy into the next layer's tile) as one.
+ * maxpool3s2: nn.MaxPool2d(3, 2) without padding, output [n][(h-3)/2+1][(w-3)/2+1][c]. */
+int32_t swk_nhwc_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t c, int32_t crop_y,
+                                 int32_t crop_x, int32_t h, int32_t w, const float *bias, float *dst, int32_t dH, int32_t dW,
+                                 int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
+int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h, int32_t w, int32_t c, float *dst);
+
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size
  * n_prev + n_curr, row-major.  Centroids are (row, col) float64 pairs; prev_hist0 = centroid of the first

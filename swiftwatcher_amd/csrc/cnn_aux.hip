@@ -1,0 +1,84 @@
+// Glue kernels of the receptive-field cropped classifier (swiftwatcher_amd/segment_classification.py): the
+// convolutions stay with MIOpen (PyTorch-ROCm), but between them PyTorch needs three passes over every activation
+// (bias add, ReLU, copy into the next layer's tile) and its NHWC max-pool kernel runs far below the memory rate.
+// Both are plain streaming jobs; they are launched on the CALLER's stream (PyTorch's current stream).
+// Layout: channels-last dense float32, tensor (n, c, h, w) = memory [n][h][w][c].
+#include "swk_internal.h"
+
+namespace swk {
+
+// dst[n][off_y + y][off_x + x][c_off + ch] = max(src[n][crop_y + y][crop_x + x][ch] + bias[ch], 0)
+// for y < h, x < w, ch < c;  src is [n][sh][sw][c], dst is [n][dH][dW][dC].  c, dC, c_off multiples of 4.
+__global__ __launch_bounds__(256) void k_bias_relu_place(const float4 *__restrict__ src, int sh, int sw, int c4, int crop_y, int crop_x,
+                                                         int h, int w, const float4 *__restrict__ bias, float4 *__restrict__ dst,
+                                                         int dH, int dW, int dC4, int off_y, int off_x, int c_off4, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % c4);
+    int64_t r = i / c4;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int64_t n = r / h;
+    const float4 v = src[((n * sh + crop_y + y) * sw + crop_x + x) * c4 + ch];
+    const float4 b = bias[ch];
+    float4 o;
+    o.x = fmaxf(v.x + b.x, 0.0f); o.y = fmaxf(v.y + b.y, 0.0f); o.z = fmaxf(v.z + b.z, 0.0f); o.w = fmaxf(v.w + b.w, 0.0f);
+    dst[((n * dH + off_y + y) * dW + off_x + x) * dC4 + c_off4 + ch] = o;
+}
+
+// MaxPool2d(3, stride 2) without padding over [n][h][w][c] -> [n][oh][ow][c], oh = (h - 3) / 2 + 1
+__global__ __launch_bounds__(256) void k_maxpool3s2(const float4 *__restrict__ src, int h, int w, int c4, float4 *__restrict__ dst,
+                                                    int oh, int ow, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % c4);
+    int64_t r = i / c4;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh);
+    const int64_t n = r / oh;
+    const float4 *p = src + ((n * h + 2 * oy) * w + 2 * ox) * c4 + ch;
+    float4 m = p[0];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float4 v = p[((int64_t)dy * w + dx) * c4];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    dst[i] = m;
+}
+
+}  // namespace swk
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int32_t swk_nhwc_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t c, int32_t crop_y,
+                                 int32_t crop_x, int32_t h, int32_t w, const float *bias, float *dst, int32_t dH, int32_t dW,
+                                 int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off)
+{
+    if (!src || !bias || !dst || n < 1 || h < 1 || w < 1 || c < 4 || (c & 3) || (dC & 3) || (c_off & 3) || crop_y < 0 || crop_x < 0 ||
+        crop_y + h > sh || crop_x + w > sw || off_y < 0 || off_x < 0 || off_y + h > dH || off_x + w > dW || c_off < 0 || c_off + c > dC ||
+        (((uintptr_t)src | (uintptr_t)bias | (uintptr_t)dst) & 15))
+        return SWK_ERR_ARG;
+    const int64_t total = (int64_t)n * h * w * (c / 4);
+    hipLaunchKernelGGL(swk::k_bias_relu_place, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)src, sh, sw, c / 4, crop_y, crop_x, h, w, (const float4 *)bias, (float4 *)dst, dH, dW, dC / 4,
+                       off_y, off_x, c_off / 4, total);
+    return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+
+int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h, int32_t w, int32_t c, float *dst)
+{
+    if (!src || !dst || n < 1 || h < 3 || w < 3 || c < 4 || (c & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return SWK_ERR_ARG;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int64_t total = (int64_t)n * oh * ow * (c / 4);
+    hipLaunchKernelGGL(swk::k_maxpool3s2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)src, h, w, c / 4, (float4 *)dst, oh, ow, total);
+    return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

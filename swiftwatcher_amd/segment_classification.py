@@ -190,6 +190,9 @@ class CroppedSqueezeNet10:
     @torch.no_grad()
     def __call__(self, tiles):
         """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input."""
+        if tiles.is_cuda and self.memory_format == torch.channels_last and all(
+                kind != "fire" or not (pad[0] or pad[1]) for kind, _, _, _, _, pad, _ in self.plan):
+            return self._forward_hip_glue(tiles)
         m = self.model
         conv2d = torch.nn.functional.conv2d
         k = tiles.shape[0]
@@ -220,6 +223,89 @@ class CroppedSqueezeNet10:
             x = dest
         s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
         return (s + self.ring_sum) / self.n_pos
+
+    def _forward_hip_glue(self, tiles):
+        """The same forward on the GPU with the convolutions alone left to MIOpen: bias + ReLU + placement into the
+        next tile is one HIP kernel per convolution output (swk_nhwc_bias_relu_place), max-pooling another
+        (swk_nhwc_maxpool3s2), both on PyTorch's current stream.  Same float32 operations per element as above."""
+        from . import _lib
+        lib = _lib.load()
+        stream = ctypes_void_p(torch.cuda.current_stream(tiles.device).cuda_stream)
+        m = self.model
+        conv2d = torch.nn.functional.conv2d
+        k = tiles.shape[0]
+        bufs, live = self._buffers(k)
+        cl = torch.channels_last
+
+        def nhwc(t):
+            return t if t.is_contiguous(memory_format=cl) else t.contiguous(memory_format=cl)
+
+        def place(e, bias, dest, crop, size, off, c_off):
+            e = nhwc(e)
+            rc = lib.swk_nhwc_bias_relu_place(stream, e.data_ptr(), k, e.shape[2], e.shape[3], e.shape[1], crop, crop, size, size,
+                                              bias.data_ptr(), dest.data_ptr(), dest.shape[2], dest.shape[3], dest.shape[1],
+                                              off, off, c_off)
+            if rc:
+                raise RuntimeError("swk_nhwc_bias_relu_place failed (%d)" % rc)
+
+        def pool(src, dst):
+            rc = lib.swk_nhwc_maxpool3s2(stream, src.data_ptr(), k, src.shape[2], src.shape[3], src.shape[1], dst.data_ptr())
+            if rc:
+                raise RuntimeError("swk_nhwc_maxpool3s2 failed (%d)" % rc)
+
+        aux = self._aux_buffers(k)
+        conv1 = m.features[0]
+        e = conv2d(nhwc(tiles), conv1.weight, None, stride=conv1.stride)
+        a, b = self.pool1_slice
+        c1buf = aux["conv1"][:k]
+        place(e, conv1.bias, c1buf, a, b - a, 0, 0)
+        x = aux["pool_in"][:k]
+        pool(c1buf, x)
+        pi = 0
+        for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
+            if kind == "pool":
+                x = aux["pool_out"][pi][:k]
+                pool(bufs[j][:k], x)
+                pi += 1
+                continue
+            sq = bufs[j][:k]
+            place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
+            e3 = conv2d(sq, layer.expand3x3.weight, None)
+            e1 = conv2d(sq, layer.expand1x1.weight, None)
+            c, cn = crop
+            c1 = layer.expand1x1.out_channels
+            if live[j] is not None:
+                dest, doff = live[j][:k], 0
+            else:
+                dest, doff = bufs[j + 1][:k], self.plan[j + 1][3]
+            place(e1, layer.expand1x1.bias, dest, c, cn, doff, 0)
+            place(e3, layer.expand3x3.bias, dest, 0, cn, doff, c1)
+            x = dest
+        s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
+        return (s + self.ring_sum) / self.n_pos
+
+    def _aux_buffers(self, batch):
+        if getattr(self, "_aux_cap", 0) >= batch:
+            return self._aux
+        dev = self.ring_sum.device
+        cl = torch.channels_last
+
+        def buf(c, h):
+            return torch.empty((batch, c, h, h), dtype=torch.float32, device=dev).contiguous(memory_format=cl)
+
+        a, b = self.pool1_slice
+        conv1_c = self.model.features[0].out_channels
+        aux = {"conv1": buf(conv1_c, b - a), "pool_in": buf(conv1_c, (b - a - 3) // 2 + 1), "pool_out": []}
+        for kind, layer, tile, off, n, pad, crop in self.plan:
+            if kind == "pool":
+                aux["pool_out"].append(buf(tile.shape[1], (tile.shape[2] - 3) // 2 + 1))
+        self._aux, self._aux_cap = aux, batch
+        return aux
+
+
+def ctypes_void_p(v):
+    import ctypes
+    return ctypes.c_void_p(v)
 
 
 def setup_model(num_classes):
