@@ -192,7 +192,8 @@ class CroppedSqueezeNet10:
         """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input."""
         if tiles.is_cuda and self.memory_format == torch.channels_last and all(
                 kind != "fire" or not (pad[0] or pad[1]) for kind, _, _, _, _, pad, _ in self.plan):
-            return self._forward_hip_glue(tiles)
+            with torch.cuda.device(tiles.device):            # the glue kernels go to this device's current stream
+                return self._forward_hip_glue(tiles)
         m = self.model
         conv2d = torch.nn.functional.conv2d
         k = tiles.shape[0]
