@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
+    ap.add_argument("--sparse-spec", type=float, default=None, help="A/B: swk_set_sparse_speculation factor (0 = stores in every pass)")
+    ap.add_argument("--norm-spec", type=float, default=None, help="A/B: swk_set_norm_speculation factor (0 = norm in every pass)")
     ap.add_argument("--classify", action="store_true",
                     help="also classify every segment inside the timed step (SqueezeNet-1.0 on PyTorch-ROCm, random-init "
                          "weights, inputs cut on the device by swk_segment_inputs): BASELINE config 3 without the tracker")
@@ -114,6 +116,10 @@ def main():
     ctx.set_ialm_groups(args.groups)
     ctx.set_eig_cus(args.eig_cus)
     ctx.set_eig_method(args.eig_method)
+    if args.sparse_spec is not None:
+        ctx.set_sparse_speculation(args.sparse_spec)
+    if args.norm_spec is not None:
+        ctx.set_norm_speculation(args.norm_spec)
     params = _lib.default_params()
     inp = _lib.Input(frames=frames.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
                      x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)

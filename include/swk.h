@@ -243,6 +243,10 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
  * stores makes the library run the batch again without the speculation, so results never depend on the factor;
  * swk_prof_redo_batches counts those reruns. */
 int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor);
+/* M-state pass only: while the last formed ||Z||_F is >= factor * tol * ||X||_F (default 64; <= 0 = never) the
+ * stopping norm is formed every other iteration only (the f16 copy of Y/mu is neither written nor read in between).
+ * A window found below the threshold right after an iteration whose norm was not formed is rerun like above. */
+int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
 /* Window groups whose eigen-solves overlap the other groups' streaming passes:
  * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */

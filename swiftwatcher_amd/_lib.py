@@ -81,6 +81,7 @@ _SIGS = {
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_sparse_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_nhwc_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6),
     "swk_nhwc_maxpool3s2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -190,6 +191,9 @@ class Context:
 
     def set_sparse_speculation(self, factor):
         self._check(self._lib.swk_set_sparse_speculation(self._h, float(factor)))
+
+    def set_norm_speculation(self, factor):
+        self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))
 
     @property
     def redo_batches(self):

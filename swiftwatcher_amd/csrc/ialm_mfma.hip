@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const IalmWin &st = b.win[w];
     if (st.done) return;
     const bool ws = st.ws != 0;                  // sparse-image stores on for this pass (k_ialm_small decides)
+    const bool ru = st.ru != 0, wu = st.wu != 0; // all of U read (full ||Z||) / written in this pass; else frames 0..3 only
     const int n = b.n, P = b.P;
     const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     d4 G[C::NPAIR];
 #pragma unroll
     for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double zz = 0.0;
+    double zz = 0.0, zz0 = 0.0;                  // sum of z^2 over frames >= 4 / frames 0..3
 
     // a block owns groups of 8 consecutive tiles = 128 pixels: every 128-byte line of the u8 planes (and every
     // pair of half lines of the f32 plane) is touched by ONE workgroup, two tiles per wave back to back
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
         const unsigned vo2 = pvalid ? ((unsigned)fr0 * ps32 + p) * 2u : kOob;     // binary16 planes
         const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
         const unsigned vo1s = ws ? vo1 : kOob;
+        const unsigned vo2r = ru ? vo2 : kOob, vo2w = wu ? vo2 : kOob;
         int xi[NK];
         double mv[NK];
         float uf[NK];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
             xi[t] = buf_ld8(rX, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
             if (MODE == 2) {
                 mv[t] = buf_ld64(rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
-                uf[t] = buf_ld16h(rU, fvalid ? vo2 : kOob, (unsigned)(4 * t) * ps32 * 2u);
+                uf[t] = buf_ld16h(rU, fvalid ? (t == 0 ? vo2 : vo2r) : kOob, (unsigned)(4 * t) * ps32 * 2u);
             }
         }
         if (MODE == 1) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                         const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}
                         const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * y0_of(x);
                         const double z = pk - uprev;                                   // :293
-                        zz += z * z;
+                        if (t == 0) zz0 += z * z; else zz += z * z;
                         y = mu * pk;                                                   // :294
                     }
                     const double u = inv_mu2 * y;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                     const bool fvalid = FULL || 4 * t < flim;
                     if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
                         buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
-                        buf_st16h((float)u, rU, fvalid ? vo2 : kOob, (unsigned)(4 * t) * ps32 * 2u);
+                        buf_st16h((float)u, rU, fvalid ? (t == 0 ? vo2 : vo2w) : kOob, (unsigned)(4 * t) * ps32 * 2u);
                     }
                     buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1s : kOob, (unsigned)(4 * t) * P32);
                 }
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
         if ((i >> 4) <= (j >> 4)) gp[idx] = sG[i * NPAD + j];
     }
     if (MODE != 0) {
+        zz = zz0 + ((MODE == 1 || ru) ? zz : 0.0);           // without all of U only the first four frames count
         for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
         __syncthreads();
         if (lane == 0) lds[NPAD * NPAD + wave] = zz;

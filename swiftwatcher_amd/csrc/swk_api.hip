@@ -46,6 +46,7 @@ struct swk_ctx {
     int ialm_variant = 0;
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
+    double norm_spec = 64.0;       // M-state pass: ||Z|| every other iteration while above 64 x tol (<= 0: every iteration)
     int ialm_groups = 0;                 // 0 = auto
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
     int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
@@ -265,6 +266,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (variant == 3) {
         b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
         b.spec = speculate ? ctx->sparse_spec : 0.0;
+        b.nspec = speculate ? ctx->norm_spec : 0.0;
         NEED(ctx, SL_SALT, elems, b.Salt);
     }
     if (want_E) NEED(ctx, SL_E, felems * 8, b.E);
@@ -369,7 +371,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // everything after the IALM runs on the main stream: join the side streams
     for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
     if (variant == 3) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
-    if (variant == 3 && b.spec > 0.0) {
+    if (variant == 3 && (b.spec > 0.0 || b.nspec > 0.0)) {
         // did any window stop right after a pass that had its sparse-image stores switched off?
         std::vector<IalmWin> hw(nwin);
         HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
@@ -531,6 +533,12 @@ int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor)
 {
     if (!ctx) return SWK_ERR_ARG;
     ctx->sparse_spec = factor;
+    return SWK_OK;
+}
+int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    ctx->norm_spec = factor;
     return SWK_OK;
 }
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)

@@ -22,6 +22,8 @@ struct IalmWin {
     int sweeps;                    // Jacobi sweeps used by the last eigen solve (diagnostic)
     int ws, ws_prev;               // M-state pass: did / does the pass of this (the previous) iteration write the sparse image
     int redo;                      // the last iteration's sparse image was not written: the window has to be run again
+    int ru, wu;                    // M-state pass: this pass reads / writes ALL of U (else frames 0..3 only)
+    double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
 };
 
 struct IalmBuffers {
@@ -39,6 +41,7 @@ struct IalmBuffers {
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;
     double spec;                   // M-state pass: sparse image written only once ||Z|| < spec * tol * ||X|| (<= 0: always)
+    double nspec;                  // M-state pass: ||Z|| formed every other iteration while above nspec * tol * ||X|| (<= 0: always)
     int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
     int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows

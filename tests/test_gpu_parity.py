@@ -204,17 +204,26 @@ def test_pass_kernels_agree_at_full_size():
 
 def test_sparse_store_speculation_never_changes_results(orc):
     """The M-state pass skips the per-iteration stores of the sparse image while ||Z|| is far above the stopping
-    threshold.  Whatever the factor -- stores always on (0), the default (16 x tol), or a factor so small that the
-    stores are still off when the iteration stops, which forces the rerun path -- the outputs are the oracle's."""
+    threshold, and further out forms ||Z|| every other iteration only.  Whatever the factors -- speculation off (0),
+    the defaults (16 / 64 x tol), or factors so small that the guess is still in force when the iteration stops,
+    which forces the rerun path -- iteration counts and outputs are the oracle's."""
     from swiftwatcher_amd import _lib, synthetic
     roi = np.concatenate([synthetic.roi_window(40 + w, 21, 64, 96, birds=3 + w, bird_len=(8, 14), bird_wid=(3, 6))
                           for w in range(3)])
     refs = [orc.window(np.ascontiguousarray(roi[w * 21:(w + 1) * 21])) for w in range(3)]
-    for factor, want_redo in ((0.0, False), (16.0, False), (1e-9, True)):
+    ref_iters = []
+    for w in range(3):
+        gray = np.stack([orc.bgr2gray(f) for f in roi[w * 21:(w + 1) * 21]]).reshape(21, -1).T
+        ref_iters.append(orc.ialm(gray, return_iters=True)[2])
+    # want_redo None: alternating to the very end reruns only the windows whose last iteration is an unformed one
+    for factor, nfactor, want_redo in ((0.0, 0.0, False), (16.0, 64.0, False), (1e-9, 0.0, True), (0.0, 1e-9, None),
+                                       (16.0, 0.0, False), (0.0, 64.0, False)):
         c = _lib.Context(0)
         c.set_sparse_speculation(factor)
+        c.set_norm_speculation(nfactor)
         res = c.batch_run(roi, 3, 21, stages=("rpca", "labels"))
-        assert (c.redo_batches > 0) == want_redo, (factor, c.redo_batches)
+        assert want_redo is None or (c.redo_batches > 0) == want_redo, (factor, nfactor, c.redo_batches)
+        assert [int(i) for i in res["iters"]] == [orc_it for orc_it in ref_iters]
         for w in range(3):
             sl = slice(w * 21, (w + 1) * 21)
             np.testing.assert_array_equal(res["rpca"][sl], refs[w]["rpca"], err_msg="factor %g window %d" % (factor, w))
