@@ -248,6 +248,10 @@ int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor);
  * A window found below the threshold right after an iteration whose norm was not formed is rerun like above. */
 int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
+/* M-state pass: algorithmic bytes per matrix element moved by all its launches since swk_prof_reset, summed over
+ * windows (each window-iteration counts X 1 + M 8 (+8 read) + U 2 or 1/8 each way + 1 when the sparse image is
+ * stored); multiply by n*P for bytes.  Meaningful for the M-state pass only. */
+int32_t swk_prof_pass_bytes_per_element(swk_ctx *ctx, double *bytes);
 /* Window groups whose eigen-solves overlap the other groups' streaming passes:
  * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */
 int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);

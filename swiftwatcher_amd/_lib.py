@@ -82,6 +82,7 @@ _SIGS = {
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_sparse_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_nhwc_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6),
     "swk_nhwc_maxpool3s2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -194,6 +195,12 @@ class Context:
 
     def set_norm_speculation(self, factor):
         self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))
+
+    @property
+    def pass_bytes_per_element(self):
+        v = ctypes.c_double(0)
+        self._check(self._lib.swk_prof_pass_bytes_per_element(self._h, ctypes.byref(v)))
+        return v.value
 
     @property
     def redo_batches(self):

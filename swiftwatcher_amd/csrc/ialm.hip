@@ -76,7 +76,7 @@ __global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda)
     s.iter = 0;
     s.sweeps = 0;
     s.ws = 1; s.ws_prev = 1; s.redo = 0;
-    s.ru = 1; s.wu = 1; s.last_ratio = 1e300;
+    s.ru = 1; s.wu = 1; s.last_ratio = 1e300; s.pass_b16 = 0;
     // an all-zero window has nothing to decompose (the reference would divide by zero)
     s.done = s.sumsq == 0 ? 1 : 0;
     if (!s.done) atomicAdd(active, 1);

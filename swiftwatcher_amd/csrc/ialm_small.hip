@@ -51,6 +51,13 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         // delivers the sum over those frames: a LOWER bound
         const bool full = st.ru != 0;
         const double ratio = sqrt(red[0]) / st.dnorm;            // :297
+        if (tid == 0) {
+            // bookkeeping for the roofline: what pass k had to move per element (M-state pass; 1/16-byte units):
+            // X 1 + M 8 written (+ 8 read after the first pass) + U 2 or 2/16 each way + the sparse image if stored
+            unsigned u = 16 + 128 + (st.wu ? 32 : 2) + (st.ws ? 16 : 0);
+            if (k >= 2) u += 128 + (st.ru ? 32 : 2);
+            st.pass_b16 += u;
+        }
         if (!full && ratio < tol && k < maxiter) {
             // the bound cannot rule out that this iteration is the last: give the window up, the host runs the
             // batch again with every norm formed

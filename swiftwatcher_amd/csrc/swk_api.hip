@@ -46,6 +46,7 @@ struct swk_ctx {
     int ialm_variant = 0;
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
+    unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 64.0;       // M-state pass: ||Z|| every other iteration while above 64 x tol (<= 0: every iteration)
     int ialm_groups = 0;                 // 0 = auto
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
@@ -396,7 +397,7 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     std::vector<IalmWin> hw(nwin);
     HIPCHK(ctx, hipMemcpy(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost));
     std::vector<int32_t> it(nwin);
-    for (int w = 0; w < nwin; ++w) { it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; }
+    for (int w = 0; w < nwin; ++w) { it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; ctx->pass_b16 += hw[w].pass_b16; }
     if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
     if (d_iters) HIPCHK(ctx, hipMemcpy(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice));
     return SWK_OK;
@@ -507,6 +508,7 @@ int32_t swk_prof_reset(swk_ctx *ctx)
     memset(ctx->prof_ms, 0, sizeof ctx->prof_ms);
     memset(ctx->prof_n, 0, sizeof ctx->prof_n);
     ctx->window_iters = 0;
+    ctx->pass_b16 = 0;
     return SWK_OK;
 }
 int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *launches)
@@ -539,6 +541,12 @@ int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor)
 {
     if (!ctx) return SWK_ERR_ARG;
     ctx->norm_spec = factor;
+    return SWK_OK;
+}
+int32_t swk_prof_pass_bytes_per_element(swk_ctx *ctx, double *bytes)
+{
+    if (!ctx || !bytes) return SWK_ERR_ARG;
+    *bytes = (double)ctx->pass_b16 / 16.0;
     return SWK_OK;
 }
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)

@@ -24,6 +24,7 @@ struct IalmWin {
     int redo;                      // the last iteration's sparse image was not written: the window has to be run again
     int ru, wu;                    // M-state pass: this pass reads / writes ALL of U (else frames 0..3 only)
     double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
+    unsigned long long pass_b16;   // algorithmic bytes per element moved by the passes 1..iter of this window, in 1/16 B
 };
 
 struct IalmBuffers {
