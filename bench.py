@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
+    ap.add_argument("--tol", type=float, default=None, help="experiments: IALM tolerance (reference: 0.001)")
+    ap.add_argument("--maxiter", type=int, default=None, help="experiments: IALM iteration cap (reference: 100)")
     ap.add_argument("--sparse-spec", type=float, default=None, help="A/B: swk_set_sparse_speculation factor (0 = stores in every pass)")
     ap.add_argument("--norm-spec", type=float, default=None, help="A/B: swk_set_norm_speculation factor (0 = norm in every pass)")
     ap.add_argument("--classify", action="store_true",
@@ -121,6 +123,10 @@ def main():
     if args.norm_spec is not None:
         ctx.set_norm_speculation(args.norm_spec)
     params = _lib.default_params()
+    if args.tol is not None:
+        params.tol = args.tol
+    if args.maxiter is not None:
+        params.maxiter = args.maxiter
     inp = _lib.Input(frames=frames.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
                      x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)
     out = _lib.Output(mem=_lib.MEM_DEVICE, seg_cap=seg_cap)
