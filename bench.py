@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--eig-method", type=int, default=0, help="0 Newton-Schulz (MFMA), 1 Jacobi")
     ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=1, help="windows in the CPU baseline sample")
+    ap.add_argument("--cpu-windows", type=int, default=3, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
     ap.add_argument("--host-input", action="store_true", help="also time a step fed from host memory (PCIe inclusive)")
     return ap.parse_args()
 
