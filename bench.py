@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
+    ap.add_argument("--integer-start", type=int, default=None, help="A/B: swk_set_integer_start (0 = f64 start pass)")
     ap.add_argument("--tol", type=float, default=None, help="experiments: IALM tolerance (reference: 0.001)")
     ap.add_argument("--maxiter", type=int, default=None, help="experiments: IALM iteration cap (reference: 100)")
     ap.add_argument("--sparse-spec", type=float, default=None, help="A/B: swk_set_sparse_speculation factor (0 = stores in every pass)")
@@ -118,6 +119,8 @@ def main():
     ctx.set_ialm_groups(args.groups)
     ctx.set_eig_cus(args.eig_cus)
     ctx.set_eig_method(args.eig_method)
+    if args.integer_start is not None:
+        ctx.set_integer_start(args.integer_start)
     if args.sparse_spec is not None:
         ctx.set_sparse_speculation(args.sparse_spec)
     if args.norm_spec is not None:

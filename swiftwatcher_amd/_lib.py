@@ -81,6 +81,7 @@ _SIGS = {
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_sparse_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_set_integer_start": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -192,6 +193,9 @@ class Context:
 
     def set_sparse_speculation(self, factor):
         self._check(self._lib.swk_set_sparse_speculation(self._h, float(factor)))
+
+    def set_integer_start(self, on):
+        self._check(self._lib.swk_set_integer_start(self._h, int(bool(on))))
 
     def set_norm_speculation(self, factor):
         self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))

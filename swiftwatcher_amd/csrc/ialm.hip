@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_ialm_stats(const uint8_t *__restrict__ 
     }
 }
 
-__global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda)
+__global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda, int use_gram8)
 {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
@@ -80,6 +80,11 @@ __global__ void k_ialm_init(IalmWin *win, int *active, int nwin, double lmbda)
     // an all-zero window has nothing to decompose (the reference would divide by zero)
     s.done = s.sumsq == 0 ? 1 : 0;
     if (!s.done) atomicAdd(active, 1);
+    // does the integer Gram matrix stand?  Only if the first shrinkage removes nothing: the largest entry of
+    // X + Y_0/mu_0 (:282; Y_0 = X/dual, :272) stays within the threshold lmbda/mu_0 (:283)
+    const double xmax = (double)s.maxv;
+    const double raw_max = xmax + s.nxt.inv_mu * (xmax / s.dual_norm);
+    s.int_gram = (use_gram8 && !s.done && raw_max <= s.nxt.thr) ? 1 : 0;
 }
 
 __device__ __forceinline__ double shrink(double raw, double thr)
@@ -271,7 +276,7 @@ void launch_ialm_stats(hipStream_t s, const IalmBuffers &b)
 
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda)
 {
-    hipLaunchKernelGGL(k_ialm_init, dim3((b.nwin + 63) / 64), dim3(64), 0, s, b.win, b.active, b.nwin, lmbda);
+    hipLaunchKernelGGL(k_ialm_init, dim3((b.nwin + 63) / 64), dim3(64), 0, s, b.win, b.active, b.nwin, lmbda, b.use_gram8);
 }
 
 template <int MODE, bool WE>

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const int w = blockIdx.y;
     const IalmWin &st = b.win[w];
     if (st.done) return;
+    if (MODE == 0 && st.int_gram) return;        // the start pass's only product already came from k_gram_u8
     const bool ws = st.ws != 0;                  // sparse-image stores on for this pass (k_ialm_small decides)
     const bool ru = st.ru != 0, wu = st.wu != 0; // all of U read (full ||Z||) / written in this pass; else frames 0..3 only
     const int n = b.n, P = b.P;

@@ -101,16 +101,21 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
 
 // Deterministic reduction of the per-block Gram partials into an LDS matrix of the given pitch.
 // The MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): the rest is mirrored.
-__device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double *G, int pitch)
+__device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double *G, int pitch, int k)
 {
     const int n = b.n, nblk = b.nblk, nred = b.nred;
+    // first iteration from the integer kernel: the slabs hold X^T X and M_1 = (1 + 1/(mu_0 dual)) X (ialm_gram8.hip);
+    // st.cur is mu_0 at this point (small_prologue has run)
+    const IalmWin &st = b.win[w];
+    double scale = 1.0;
+    if (k == 0 && st.int_gram) { const double s1 = 1.0 + st.cur.inv_mu / st.dual_norm; scale = s1 * s1; }
     const double *gp = b.gpart + (int64_t)w * nblk * n * n;
     for (int idx = threadIdx.x; idx < n * n; idx += kSmallThreads) {
         const int i = idx / n, j = idx - i * n;
         const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
         double acc = 0.0;
         for (int bk = 0; bk < nred; ++bk) acc += gp[(int64_t)bk * n * n + src];
-        G[i * pitch + j] = acc;
+        G[i * pitch + j] = acc * scale;
     }
 }
 
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         // ---- Y = G (padded with zeros), Z = I ----
         for (int idx = tid; idx < NPAD * PITCH; idx += kSmallThreads) { Y[idx] = 0.0; Z[idx] = 0.0; }
         __syncthreads();
-        gram_reduce(b, w, Y, PITCH);
+        gram_reduce(b, w, Y, PITCH, k);
         __syncthreads();
         // s = ||G||_F (fixed-order reduction)
         double acc = 0.0;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
     }
     // ---- Jacobi (reference method / fallback) ----
     double *G = sm, *V = sm + kMaxN * kJac, *Wm = sm + 2 * kMaxN * kJac;
-    gram_reduce(b, w, G, kJac);
+    gram_reduce(b, w, G, kJac, k);
     __syncthreads();
     int sweeps = 0;
     jacobi_invsqrt(G, V, Wm, n, cs, ints, wgt, ints + 36, &sweeps);

@@ -46,6 +46,7 @@ struct swk_ctx {
     int ialm_variant = 0;
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
+    int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 64.0;       // M-state pass: ||Z|| every other iteration while above 64 x tol (<= 0: every iteration)
     int ialm_groups = 0;                 // 0 = auto
@@ -328,7 +329,12 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     }
     const int check_from = 6;     // no window converges earlier (mu grows 1.5x per iteration)
     for (int g = 0; g < ngroups; ++g) {
-        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_stats(s, grp[g].b); launch_ialm_init(s, grp[g].b, lmbda); }
+        // window statistics (||X||_F, max) and, for the M-state pass, the first Gram matrix in the same read of X
+        // on the integer matrix cores; windows it does not cover get the f64 start pass below
+        grp[g].b.use_gram8 = (variant == 3 && ctx->use_gram8 && gram_u8_supported(grp[g].b)) ? 1 : 0;
+        { Timed t(ctx, SWK_K_IALM_STATS);
+          if (grp[g].b.use_gram8) launch_gram_u8(s, grp[g].b); else launch_ialm_stats(s, grp[g].b);
+          launch_ialm_init(s, grp[g].b, lmbda); }
         // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
         // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
         { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0); }
@@ -535,6 +541,12 @@ int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor)
 {
     if (!ctx) return SWK_ERR_ARG;
     ctx->sparse_spec = factor;
+    return SWK_OK;
+}
+int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    ctx->use_gram8 = on ? 1 : 0;
     return SWK_OK;
 }
 int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor)

@@ -24,6 +24,7 @@ struct IalmWin {
     int redo;                      // the last iteration's sparse image was not written: the window has to be run again
     int ru, wu;                    // M-state pass: this pass reads / writes ALL of U (else frames 0..3 only)
     double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
+    int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
     unsigned long long pass_b16;   // algorithmic bytes per element moved by the passes 1..iter of this window, in 1/16 B
 };
 
@@ -42,6 +43,7 @@ struct IalmBuffers {
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;
     double spec;                   // M-state pass: sparse image written only once ||Z|| < spec * tol * ||X|| (<= 0: always)
+    int use_gram8;                 // k_gram_u8 ran: k_ialm_init decides per window whether its result stands
     double nspec;                  // M-state pass: ||Z|| formed every other iteration while above nspec * tol * ||X|| (<= 0: always)
     int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
@@ -58,6 +60,9 @@ void launch_select_sparse(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);
 // sums the nblk Gram partial slabs of every live window into slab 0, in fixed order, chip-wide
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b);
+// ialm_gram8.hip: exact X^T X, sum of squares and max of every window on the i8 matrix cores
+bool gram_u8_supported(const IalmBuffers &b);
+void launch_gram_u8(hipStream_t s, const IalmBuffers &b);
 void launch_planes_to_pn(hipStream_t s, const double *planes, double *out, int nwin, int n, int P, int64_t pstride, int fpad);
 void launch_rpca_epilogue(hipStream_t s, const double *E, int64_t count, uint8_t *S);
 int  ialm_pass_nblk(int variant, int n, int P, int nwin);

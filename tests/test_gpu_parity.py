@@ -202,6 +202,27 @@ def test_pass_kernels_agree_at_full_size():
     assert a["segs"].tobytes() == b["segs"].tobytes()
 
 
+def test_integer_start_matches_f64_start():
+    """First Gram matrix from the i8 matrix cores (exact X^T X, scaled) against the f64 start pass: same iteration
+    counts, sparse images and regions; a toy window whose first shrinkage is active must fall back by itself."""
+    from swiftwatcher_amd import _lib, synthetic
+    roi = np.concatenate([synthetic.roi_window(90 + w, 64, 212, 424, birds=3 + 4 * w) for w in range(2)] +
+                         [synthetic.roi_window(95, 64, 212, 424, birds=5, null_frames=3)])
+    out = []
+    for on in (1, 0):
+        c = _lib.Context(0)
+        c.set_integer_start(on)
+        out.append(c.batch_run(roi, 3, 64, stages=("rpca", "labels")))
+        small = synthetic.roi_window(7, 7, 16, 16, birds=1, bird_len=(4, 6), bird_wid=(2, 3))     # lmbda / mu_0 < max(X)
+        out.append(c.batch_run(small, 1, 7, stages=("rpca",)))
+        c.close()
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        np.testing.assert_array_equal(a["rpca"], b["rpca"])
+    np.testing.assert_array_equal(out[0]["labels"], out[2]["labels"])
+    assert out[0]["segs"].tobytes() == out[2]["segs"].tobytes()
+
+
 def test_sparse_store_speculation_never_changes_results(orc):
     """The M-state pass skips the per-iteration stores of the sparse image while ||Z|| is far above the stopping
     threshold, and further out forms ||Z|| every other iteration only.  Whatever the factors -- speculation off (0),
