@@ -325,9 +325,20 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
     if (tid < kSH * 3) s_nz[tid] = 0u;
     __syncthreads();
     // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71; its nonzero pixels also go into row bit masks ----
-    const bool interior = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W &&
-                          (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
-    if (interior) {
+    const bool inside = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W;
+    const bool interior = inside && (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
+    if (inside && !interior && (W & 1) == 0 && (((uintptr_t)img) & 1) == 0) {
+        // window inside the image but rows only 2-byte aligned (e.g. W = 214): 16-bit loads, no border arithmetic
+        for (int i = tid; i < kSH * (kSP / 2); i += 256) {
+            const int sr = i / (kSP / 2), q = i - sr * (kSP / 2);
+            const uint32_t v = *(const uint16_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 2 * q);
+            ((uint16_t *)s_src)[i] = (uint16_t)v;
+            if (v) {
+                const uint32_t two = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u);
+                atomicOr(&s_nz[sr * 3 + (q >> 4)], two << (2 * (q & 15)));
+            }
+        }
+    } else if (interior) {
         for (int i = tid; i < kSH * (kSP / 4); i += 256) {
             const int sr = i / (kSP / 4), q = i - sr * (kSP / 4);
             const uint32_t v = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
