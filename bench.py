@@ -225,7 +225,12 @@ def main():
                          "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
                          "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
                          "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
-                         "pass_variant": variant},
+                         "pass_variant": variant,
+                         # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
+                         # replaces): informational, NOT what "achieved" uses
+                         "survey_pricing": {"bytes_per_element_iteration": 33,
+                                            "achieved": round(33.0 * elems * float(it_host.sum()) * args.steps / (pass_ms * 1e-3) / 1e9, 1)
+                                            if pass_ms > 0 else 0.0}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if isinstance(v, tuple)},
         }
         if args.host_input:
