@@ -202,6 +202,21 @@ def test_pass_kernels_agree_at_full_size():
     assert a["segs"].tobytes() == b["segs"].tobytes()
 
 
+@pytest.mark.parametrize("n,Hc,Wc", [(1, 300, 400), (2, 240, 320), (3, 200, 256), (17, 96, 128), (33, 64, 96), (49, 64, 80)])
+def test_window_sizes_between_the_mfma_block_counts(ctx, orc, n, Hc, Wc):
+    """Frames per window that are not multiples of 16 (padded MFMA blocks, 1..4 of them), down to a single frame."""
+    from swiftwatcher_amd import synthetic
+    roi = synthetic.roi_window(500 + n, n, Hc, Wc, birds=3, bird_len=(10, 16), bird_wid=(4, 8))
+    res = ctx.batch_run(roi, 1, n)
+    ref = orc.window(roi)
+    gray = np.stack([orc.bgr2gray(f) for f in roi]).reshape(n, -1).T
+    assert int(res["iters"][0]) == orc.ialm(gray, return_iters=True)[2]
+    for key in ("gray", "rpca", "opened", "labels"):
+        np.testing.assert_array_equal(res[key], ref[key], err_msg=key)
+    for i in range(n):
+        assert _segs(res, i) == _orc_segs(ref["segments"][i])
+
+
 def test_integer_start_matches_f64_start():
     """First Gram matrix from the i8 matrix cores (exact X^T X, scaled) against the f64 start pass: same iteration
     counts, sparse images and regions; a toy window whose first shrinkage is active must fall back by itself."""
