@@ -219,66 +219,11 @@ void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint
 }
 
 // ---------------------------------------------------------------------------------
-// Tile occupancy of the sparse image: flags[f][tile] = 1 when the tile's source window (tile + 5-px halo)
-// holds a nonzero pixel.  One dword (4 pixels) per thread; flags are plain byte stores of 1 (every writer
-// writes the same value).  About half of the 32x64 tiles of a frame are empty: the fused kernel returns
-// at once for those and their outputs stay at the zero the buffers were cleared to.
-// ---------------------------------------------------------------------------------
-
-// marks every tile whose source window (tile + halo) contains pixel range [p, p + cnt) of the frame, cnt <= 4
-__device__ __forceinline__ void mark_tiles(uint8_t *fl, int p, int cnt, int H, int W, int ntx)
-{
-    const int r = p / W, c = p - r * W;          // a short range may wrap to the next row: widen the column range
-    int c_lo = c, c_hi = c + cnt - 1, r_hi = r;
-    if (c_hi >= W) { c_lo = 0; c_hi = W - 1; r_hi = r + 1 < H ? r + 1 : H - 1; }
-    const int tr0 = (r - kHalo > 0 ? r - kHalo : 0) / kTH, tr1 = (r_hi + kHalo < H - 1 ? r_hi + kHalo : H - 1) / kTH;
-    const int tc0 = (c_lo - kHalo > 0 ? c_lo - kHalo : 0) / kTW, tc1 = (c_hi + kHalo < W - 1 ? c_hi + kHalo : W - 1) / kTW;
-    for (int tr = tr0; tr <= tr1; ++tr)
-        for (int tc = tc0; tc <= tc1; ++tc)
-            if (!fl[tr * ntx + tc]) fl[tr * ntx + tc] = 1;       // mostly a cached read: hundreds of words mark the same tile
-}
-
-// VEC = 16: four uint4 loads in flight per thread; VEC = 4 / 1: one word per thread (unaligned or odd-sized planes)
-template <int VEC>
-__global__ __launch_bounds__(256) void k_tile_flags(const uint8_t *__restrict__ src, int H, int W, int ntx, int nty,
-                                                    uint8_t *__restrict__ flags)
-{
-    const int f = blockIdx.y;
-    const int P = H * W;
-    const uint8_t *img = src + (int64_t)f * P;
-    uint8_t *fl = flags + (int64_t)f * ntx * nty;
-    if (VEC == 16) {
-        const int nv = P / 16;
-        const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = i0 + k < nv ? ((const uint4 *)img)[i0 + k] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!(v[k].x | v[k].y | v[k].z | v[k].w)) continue;
-            const int p = (i0 + k) * 16;
-            if (v[k].x) mark_tiles(fl, p, 4, H, W, ntx);
-            if (v[k].y) mark_tiles(fl, p + 4, 4, H, W, ntx);
-            if (v[k].z) mark_tiles(fl, p + 8, 4, H, W, ntx);
-            if (v[k].w) mark_tiles(fl, p + 12, 4, H, W, ntx);
-        }
-        return;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P / VEC) return;
-    uint32_t v;
-    if (VEC == 4) v = ((const uint32_t *)img)[i];
-    else v = img[i];
-    if (!v) return;
-    mark_tiles(fl, i * VEC, VEC, H, W, ntx);
-}
-
-// ---------------------------------------------------------------------------------
 // Fused hot-path kernel: bilateral (radius 3, 29 taps) -> to-zero threshold -> 3x3 opening, one 32x64 output
 // tile per workgroup.  Opening needs the thresholded image on a 2-px ring, the bilateral filter the sparse image
 // 3 px beyond that: a 42-row source tile in LDS (80 columns: the window starts 8 px left of the tile so interior
 // tiles load it as aligned dwords).  The stage is instruction-bound, so the work is made as sparse as the data:
-//   * empty tiles never start (tile flags), outputs are pre-cleared;
+//   * outputs are pre-cleared and a tile whose source window is all zero ends right after loading it;
 //   * the nonzero pixels of the source tile are kept as one 80-bit mask per row; shifts and ORs of those masks give
 //     the ring cells whose 7x7 neighbourhood holds any nonzero pixel, and only those cells -- listed from the set
 //     bits -- run the 29-tap loop (a cell with an all-zero neighbourhood filters to 0);
@@ -296,10 +241,8 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
                                                       const int8_t *__restrict__ tdr, const int8_t *__restrict__ tdc,
                                                       int maxk, int use_fma, int thresh,
                                                       uint8_t *__restrict__ bil_out, uint8_t *__restrict__ thr_out,
-                                                      uint8_t *__restrict__ open_out, const uint8_t *__restrict__ flags)
+                                                      uint8_t *__restrict__ open_out)
 {
-    // empty tile (source window all zero): every stage outputs zero, which the buffers already hold
-    if (flags && !flags[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
     __shared__ __attribute__((aligned(16))) uint8_t s_src[kSH * kSP];
     __shared__ uint32_t s_nz[kSH * 3];             // per source row: 80-bit mask of its nonzero pixels
     __shared__ unsigned long long s_hlo[kSH];      // per source row: bit lc = some nonzero among source columns lc+3 .. lc+9
@@ -315,16 +258,10 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
     const int r0 = blockIdx.y * kTH, c0 = blockIdx.x * kTW;
     const uint8_t *img = src + (int64_t)f * H * W;
     if (tid == 0) { s_count = 0; s_er_any = 0; }
-    for (int i = tid; i < 256; i += 256) s_cw[i] = color_w[i];
-    if (tid < maxk) {
-        s_sw[tid] = space_w[tid];
-        s_ofs[tid] = (int)tdr[tid] * kSP + (int)tdc[tid];
-    }
-    for (int i = tid; i < kBH * kBW / 4; i += 256) ((uint32_t *)s_thr)[i] = 0u;
-    for (int i = tid; i < kEH * kEW / 4; i += 256) ((uint32_t *)s_er)[i] = 0u;
     if (tid < kSH * 3) s_nz[tid] = 0u;
     __syncthreads();
     // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71; its nonzero pixels also go into row bit masks ----
+    int seen = 0;                                  // this thread loaded a nonzero pixel
     const bool inside = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W;
     const bool interior = inside && (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
     if (inside && !interior && (W & 1) == 0 && (((uintptr_t)img) & 1) == 0) {
@@ -334,6 +271,7 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
             const uint32_t v = *(const uint16_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 2 * q);
             ((uint16_t *)s_src)[i] = (uint16_t)v;
             if (v) {
+                seen = 1;
                 const uint32_t two = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u);
                 atomicOr(&s_nz[sr * 3 + (q >> 4)], two << (2 * (q & 15)));
             }
@@ -344,6 +282,7 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
             const uint32_t v = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
             ((uint32_t *)s_src)[i] = v;
             if (v) {
+                seen = 1;
                 const uint32_t nib = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) |
                                      ((v & 0xff000000u) ? 8u : 0u);
                 atomicOr(&s_nz[sr * 3 + (q >> 3)], nib << (4 * (q & 7)));
@@ -356,10 +295,18 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
             // cell holds img[reflect101(coordinate)]; cells far outside the image are never consumed
             const uint8_t v = img[reflect101(r0 - kHalo + sr, H) * W + reflect101(c0 - kSX + sc, W)];
             s_src[i] = v;
-            if (v) atomicOr(&s_nz[sr * 3 + (sc >> 5)], 1u << (sc & 31));
+            if (v) { seen = 1; atomicOr(&s_nz[sr * 3 + (sc >> 5)], 1u << (sc & 31)); }
         }
     }
-    __syncthreads();
+    // empty source window: every stage outputs zero, which the (cleared) buffers already hold
+    if (!__syncthreads_or(seen)) return;
+    for (int i = tid; i < 256; i += 256) s_cw[i] = color_w[i];
+    if (tid < maxk) {
+        s_sw[tid] = space_w[tid];
+        s_ofs[tid] = (int)tdr[tid] * kSP + (int)tdc[tid];
+    }
+    for (int i = tid; i < kBH * kBW / 4; i += 256) ((uint32_t *)s_thr)[i] = 0u;
+    for (int i = tid; i < kEH * kEW / 4; i += 256) ((uint32_t *)s_er)[i] = 0u;
     // ---- horizontal 7-wide OR, one source row per thread, as shifts of the row mask ----
     if (tid < kSH) {
         const unsigned long long lo = (unsigned long long)s_nz[tid * 3] | ((unsigned long long)s_nz[tid * 3 + 1] << 32);
@@ -465,7 +412,7 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
 }
 
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
-                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out, uint8_t *flags)
+                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out)
 {
     const int ntx = (W + kTW - 1) / kTW, nty = (H + kTH - 1) / kTH;
     const size_t plane = (size_t)F * H * W;
@@ -473,35 +420,13 @@ void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W,
     (void)hipMemsetAsync(open_out, 0, plane, s);
     if (bil_out) (void)hipMemsetAsync(bil_out, 0, plane, s);
     if (thr_out) (void)hipMemsetAsync(thr_out, 0, plane, s);
-    if (flags) {
-        // tile occupancy first, so that empty tiles need no work at all
-        (void)hipMemsetAsync(flags, 0, (size_t)F * ntx * nty, s);
-        const int P = H * W;
-        const bool vec4 = (P % 4 == 0) && (((uintptr_t)src & 3) == 0);
-        const bool vec16 = (P % 16 == 0) && (((uintptr_t)src & 15) == 0);
-        for (int f0 = 0; f0 < F; f0 += 32768) {
-            const int fc = F - f0 < 32768 ? F - f0 : 32768;
-            if (vec16)
-                hipLaunchKernelGGL(k_tile_flags<16>, dim3((P / 64 + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
-                                   flags + (size_t)f0 * ntx * nty);
-            else if (vec4)
-                hipLaunchKernelGGL(k_tile_flags<4>, dim3((P / 4 + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
-                                   flags + (size_t)f0 * ntx * nty);
-            else
-                hipLaunchKernelGGL(k_tile_flags<1>, dim3((P + 255) / 256, fc), dim3(256), 0, s, src + (int64_t)f0 * P, H, W, ntx, nty,
-                                   flags + (size_t)f0 * ntx * nty);
-        }
-    }
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
         const int64_t o = (int64_t)f0 * H * W;
         hipLaunchKernelGGL(k_filter_fused, dim3(ntx, nty, fc), dim3(256), 0, s,
                            src + o, H, W, t.color_w, t.space_w, t.tap_dr, t.tap_dc, t.maxk, use_fma, thresh,
-                           bil_out ? bil_out + o : nullptr, thr_out ? thr_out + o : nullptr, open_out + o,
-                           flags ? flags + (size_t)f0 * ntx * nty : nullptr);
+                           bil_out ? bil_out + o : nullptr, thr_out ? thr_out + o : nullptr, open_out + o);
     }
 }
-
-size_t filter_flags_bytes(int F, int H, int W) { return (size_t)F * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH); }
 
 }  // namespace swk

@@ -18,7 +18,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_TILEFLAGS, SL_SALT, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_SALT, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -651,9 +651,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
 
     rc = ensure_bilateral(ctx, p->bil_d, p->bil_sigma_color, p->bil_sigma_space);
     if (rc) return rc;
-    uint8_t *dflags;
-    NEED(ctx, SL_TILEFLAGS, filter_flags_bytes(F, H, W), dflags);
-    { Timed t(ctx, SWK_K_FILTER); launch_filter_fused(s, dS, F, H, W, ctx->bil, p->bil_fma, p->thresh, dBil, dThr, dOpen, dflags); }
+    { Timed t(ctx, SWK_K_FILTER); launch_filter_fused(s, dS, F, H, W, ctx->bil, p->bil_fma, p->thresh, dBil, dThr, dOpen); }
 
     CclBuffers cb{};
     rc = ensure_ccl(ctx, F, H, W, &cb);

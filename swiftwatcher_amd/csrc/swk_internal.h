@@ -82,9 +82,7 @@ void launch_thresh(hipStream_t s, const uint8_t *src, int64_t count, int thresh,
 void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint8_t *dst);
 // fused bilateral (radius 3) + to-zero threshold + 3x3 opening; optional intermediates
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
-                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out,
-                         uint8_t *tile_flags /* [F][tiles] workspace, or null: process every tile */);
-size_t filter_flags_bytes(int F, int H, int W);
+                         int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out);
 
 // classify_input.hip
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
