@@ -165,3 +165,36 @@ class FrameQueue(deque):
         segment_images = [img.extract_segment_images(rps, frame, min_seg_size, crop_region)
                           for frame, rps in zip(self.get_queue(), regionprops_lists)]
         self.store_segmented_queue(regionprops_lists, segment_images)
+
+
+def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, params=None):
+    """Several FrameQueue-fuls in ONE library call.  windows: list of (frames, frame_numbers, timestamps) triples as
+    FrameReader.get_n_frames returns them (oldest frame first), all of the same length n.  Returns one list of Frame
+    objects per window in POP order (oldest first, the order __main__.py:81-92 consumes them), segments attached
+    exactly as preprocess_queue + segment_queue would have (data_structures.py:171-217).  Windows are independent in
+    the reference too (the queue is emptied between them), so batching changes nothing but the launch count."""
+    if not windows:
+        return []
+    n = len(windows[0][0])
+    (x0, y0), (x1, y1) = crop_region
+    stack = np.empty((len(windows) * n, y1 - y0, x1 - x0) + windows[0][0][0].shape[2:], np.uint8)
+    for w, (frames, _, _) in enumerate(windows):
+        if len(frames) != n:
+            raise ValueError("every window needs the same number of frames")
+        for k, f in enumerate(frames):                       # queue index 0 = newest = last frame read (:134)
+            stack[w * n + (n - 1 - k)] = f[y0:y1, x0:x1]
+    ctx = _lib.default_context(device)
+    res = ctx.batch_run(stack, len(windows), n, params=params, stages=())
+    if np.any(res["nseg"] > res["segs"].shape[1]):
+        raise _lib.SwkError("more regions in a frame than seg_cap")
+    out = []
+    for w, (frames, numbers, stamps) in enumerate(windows):
+        popped = []
+        for k in range(n):                                   # oldest first
+            slot = w * n + (n - 1 - k)
+            fr = Frame(frames[k], numbers[k], stamps[k])
+            props = img.regionprops_from_records(res["segs"][slot, :res["nseg"][slot]])
+            fr.set_segments(props, img.extract_segment_images(props, frames[k], min_seg_size, crop_region))
+            popped.append(fr)
+        out.append(popped)
+    return out

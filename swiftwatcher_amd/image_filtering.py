@@ -132,12 +132,15 @@ class RegionProps:
 def regionprops_from_records(records):
     """swk_segment records -> RegionProps list.  The centroid is sum/area in float64, which is
     bit-identical to skimage's coords.mean(axis=0)."""
-    out = []
-    for s in records:
-        area = int(s["area"])
-        out.append(RegionProps(int(s["label"]), (int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"])),
-                               (int(s["sum_r"]) / area, int(s["sum_c"]) / area), area))
-    return out
+    if len(records) == 0:
+        return []
+    area = records["area"].astype(np.float64)
+    cr = (records["sum_r"].astype(np.float64) / area).tolist()
+    cc = (records["sum_c"].astype(np.float64) / area).tolist()
+    return [RegionProps(lab, (r0, c0, r1, c1), (a, b), ar)
+            for lab, r0, c0, r1, c1, ar, a, b in zip(records["label"].tolist(), records["r0"].tolist(), records["c0"].tolist(),
+                                                     records["r1"].tolist(), records["c1"].tolist(), records["area"].tolist(),
+                                                     cr, cc)]
 
 
 def get_segment_properties(frame):

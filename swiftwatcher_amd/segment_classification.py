@@ -382,14 +382,30 @@ class SegmentClassifier:
         return x
 
     @torch.no_grad()
+    def _bucket(self, k):
+        """Batch size the network is run at for k inputs: MIOpen searches for kernels once per tensor shape (seconds),
+        and a counting loop hands over a different number of segments every call -- so on the GPU the batch is
+        padded to one of three sizes (64, 512, batch_size).  The padding rows are scored and thrown away."""
+        if self.device.type != "cuda":
+            return k
+        for b in (64, 512):
+            if k <= b < self.batch_size:
+                return b
+        return max(self.batch_size, k)
+
+    def _run(self, x, k):
+        """Scores of the first k rows of x (x has _bucket(k) rows)."""
+        return (self.cropped(x) if self.cropped is not None else self.model(x))[:k]
+
     def scores(self, segment_images):
         out = []
         for i in range(0, len(segment_images), self.batch_size):
             chunk = segment_images[i:i + self.batch_size]
-            if self.cropped is not None:
-                out.append(self.cropped(self.preprocess(chunk, window=True)))
-            else:
-                out.append(self.model(self.preprocess(chunk)))
+            k, b = len(chunk), self._bucket(len(chunk))
+            x = self.preprocess(chunk, window=self.cropped is not None)
+            if b != k:
+                x = torch.cat([x, x[:1].expand(b - k, -1, -1, -1)])
+            out.append(self._run(x, k))
         return torch.cat(out) if out else torch.zeros((0, 2), device=self.device)
 
     @torch.no_grad()
@@ -418,13 +434,30 @@ class SegmentClassifier:
             k = min(bs, total - first)
             if k <= 0:
                 break
-            xb = x[:k]
-            scores.append(self.cropped(xb) if self.cropped is not None else self.model(xb))
+            scores.append(self._run(x[:self._bucket(k)], k).clone())     # rows past k hold an earlier chunk: scored, dropped
             frames_of.append(fidx[:k].clone())
             first += k
         if not scores:
             return torch.zeros((0, 2), device=self.device), torch.zeros((0,), dtype=torch.int32, device=self.device)
         return torch.cat(scores), torch.cat(frames_of)
+
+    def classify_frames(self, frames):
+        """__call__ for many frames with ONE scoring batch: every frame's segments replaced by the kept ones,
+        relabelled 1..k per frame (:41-42)."""
+        segs = [s for fr in frames for s in fr.segments]
+        if not segs:
+            return
+        pred = torch.max(self.scores([s.segment_image for s in segs]), 1)[1].cpu().numpy()
+        i = 0
+        for fr in frames:
+            kept = []
+            for s in fr.segments:
+                if pred[i] == 1:
+                    kept.append(s)
+                i += 1
+            for j, s in enumerate(kept):
+                s.label = j + 1
+            fr.segments = kept
 
     def __call__(self, segments):
         """:26-44: keep segments whose argmax is class 1 (ties / all-zero scores give 0 and are

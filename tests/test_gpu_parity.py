@@ -523,3 +523,9 @@ def test_swift_count_on_a_clip_matches_cpu_pipeline(orc):
     assert [(e[-1].parent_frame_number, len(e)) for e in events] == [(e[-1].parent_frame_number, len(e)) for e in tracker.detected_events]
     assert count == ec.count_swifts(tracker.detected_events)
     assert len(events) >= 1
+    # several queue-fuls per GPU call: same frames to the tracker in the same order, so the same events
+    for wpc in (2, 8):
+        count_b, events_b = pipeline.count_swifts(list(clip), crop_region, roi_mask, windows_per_call=wpc)
+        assert count_b == count
+        assert [[(s.parent_frame_number, s.label, s.bbox, s.centroid) for s in e] for e in events_b] == \
+               [[(s.parent_frame_number, s.label, s.bbox, s.centroid) for s in e] for e in events]
