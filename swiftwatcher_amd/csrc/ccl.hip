@@ -477,11 +477,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_ccl_frame(const uint8_t *__re
     }
     // ---- label plane ----
     auto label_of = [&](int idx) -> int {
-        const int r = idx / W, c = idx - r * W;
-        if (by_runs) {
-            const int us = run_first(fgr, idx, r * W) - r * W;
-            return rlab[rank_of(pix_id(r, us, W, Wb, order))];
-        }
+        const int r = idx / W, c = idx - r * W;                   // dense-frame path only (runs paint their own labels)
         const int id = pix_id(r, c, W, Wb, order);
         int root = __hip_atomic_load(&par[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
