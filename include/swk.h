@@ -243,9 +243,11 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
  * stores makes the library run the batch again without the speculation, so results never depend on the factor;
  * swk_prof_redo_batches counts those reruns. */
 int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor);
-/* M-state pass only: while the last formed ||Z||_F is >= factor * tol * ||X||_F (default 64; <= 0 = never) the
+/* M-state pass only: while the last formed ||Z||_F is >= factor * tol * ||X||_F (default 256; <= 0 = never) the
  * stopping norm is formed every other iteration only (the f16 copy of Y/mu is neither written nor read in between).
- * A window found below the threshold right after an iteration whose norm was not formed is rerun like above. */
+ * In between, the norm over frames 0..3 is still formed: a lower bound that proves the skipped iteration did not
+ * stop; a window where it cannot is rerun like above.  After a rerun the guess that failed stays off for the next
+ * 64 batches of the context (the windows of one video behave alike). */
 int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
 /* M-state pass only: 1 (default) = statistics and the first iteration's Gram matrix come from one read of X on the
  * integer matrix cores wherever the first shrinkage provably removes nothing; 0 = always the f64 start pass. */

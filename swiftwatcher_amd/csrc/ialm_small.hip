@@ -61,13 +61,13 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         if (!full && ratio < tol && k < maxiter) {
             // the bound cannot rule out that this iteration is the last: give the window up, the host runs the
             // batch again with every norm formed
-            if (tid == 0) { st.iter = k; st.done = 1; st.redo = 1; atomicSub(b.active, 1); }
+            if (tid == 0) { st.iter = k; st.done = 1; st.redo |= 2; atomicSub(b.active, 1); }
             return false;
         }
         if ((full && ratio < tol) || k >= maxiter) {
             // the answer's sparse image is the one pass k-1 wrote (ialm_mfma.hip, M-state pass): if that pass ran
             // with its stores switched off, the speculation below failed and the host runs the batch again
-            if (tid == 0) { st.iter = k; st.done = 1; if (!st.ws_prev) st.redo = 1; atomicSub(b.active, 1); }
+            if (tid == 0) { st.iter = k; st.done = 1; if (!st.ws_prev) st.redo |= 1; atomicSub(b.active, 1); }
             return false;
         }
         if (tid == 0) {

@@ -48,7 +48,8 @@ struct swk_ctx {
     int64_t redo_batches = 0;
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
-    double norm_spec = 64.0;       // M-state pass: ||Z|| every other iteration while above 64 x tol (<= 0: every iteration)
+    double norm_spec = 256.0;      // M-state pass: ||Z|| every other iteration while above 256 x tol (<= 0: every iteration)
+    int sparse_backoff = 0, norm_backoff = 0;   // batches for which a guess stays off after it failed (same video, same behaviour)
     int ialm_groups = 0;                 // 0 = auto
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
     int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
@@ -267,8 +268,12 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_Y, felems * 8, b.Y);
     if (variant == 3) {
         b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
-        b.spec = speculate ? ctx->sparse_spec : 0.0;
-        b.nspec = speculate ? ctx->norm_spec : 0.0;
+        b.spec = (speculate && ctx->sparse_backoff == 0) ? ctx->sparse_spec : 0.0;
+        b.nspec = (speculate && ctx->norm_backoff == 0) ? ctx->norm_spec : 0.0;
+        if (speculate) {
+            if (ctx->sparse_backoff > 0) ctx->sparse_backoff -= 1;
+            if (ctx->norm_backoff > 0) ctx->norm_backoff -= 1;
+        }
         NEED(ctx, SL_SALT, elems, b.Salt);
     }
     if (want_E) NEED(ctx, SL_E, felems * 8, b.E);
@@ -383,10 +388,13 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         std::vector<IalmWin> hw(nwin);
         HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
-        bool redo = false;
-        for (int w = 0; w < nwin; ++w) redo = redo || hw[w].redo != 0;
+        int redo = 0;
+        for (int w = 0; w < nwin; ++w) redo |= hw[w].redo;
         if (redo) {
+            // windows of one video behave alike: a guess that failed stays off for the next batches
             ctx->redo_batches += 1;
+            if (redo & 1) ctx->sparse_backoff = 64;
+            if (redo & 2) ctx->norm_backoff = 64;
             return run_ialm(ctx, dX, nwin, n, P, lmbda, tol, maxiter, want_A, want_E, dS, h_iters, d_iters, false);
         }
     }

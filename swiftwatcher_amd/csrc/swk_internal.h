@@ -21,7 +21,8 @@ struct IalmWin {
     int done;
     int sweeps;                    // Jacobi sweeps used by the last eigen solve (diagnostic)
     int ws, ws_prev;               // M-state pass: did / does the pass of this (the previous) iteration write the sparse image
-    int redo;                      // the last iteration's sparse image was not written: the window has to be run again
+    int redo;                      // the window has to be run again: bit 0 = the last iteration's sparse image was not
+                                   // written, bit 1 = a partial norm could not rule out that an iteration was the last
     int ru, wu;                    // M-state pass: this pass reads / writes ALL of U (else frames 0..3 only)
     double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
     int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
