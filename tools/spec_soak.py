@@ -8,6 +8,7 @@ from swiftwatcher_amd import _lib, synthetic
 rng = np.random.default_rng(1)
 a = _lib.Context(0)
 b = _lib.Context(0); b.set_sparse_speculation(0); b.set_norm_speculation(0); b.set_integer_start(0)
+c = _lib.Context(0); c.set_ialm_variant(2)          # A/Y-state pass: U never leaves f64
 cases = mism = 0
 iters = []
 for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
@@ -25,6 +26,10 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     if a.redo_batches != before:
         print("RERUN trial", trial, "n", n, "roi", Hc, Wc, "nwin", nwin, "birds", birds, "noise", noise, "iters", ra["iters"].tolist())
     rb = b.batch_run(roi, nwin, n, stages=("rpca", "labels"))
+    rc = c.batch_run(roi, nwin, n, stages=("rpca", "labels"))
+    if not (np.array_equal(ra["iters"], rc["iters"]) and np.array_equal(ra["rpca"], rc["rpca"])):
+        mism += 1
+        print("MISMATCH vs A/Y-state trial", trial, n, Hc, Wc, noise, ra["iters"], rc["iters"], int((ra["rpca"] != rc["rpca"]).sum()))
     cases += nwin
     iters += [int(i) for i in ra["iters"]]
     ok = np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["rpca"], rb["rpca"]) and np.array_equal(ra["labels"], rb["labels"])
