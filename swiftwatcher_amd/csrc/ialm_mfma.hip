@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const bool ru = st.ru != 0, wu = st.wu != 0; // all of U read (full ||Z||) / written in this pass; else frames 0..3 only
     const int n = b.n, P = b.P;
     const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
+    constexpr unsigned ROWSTEP = 128u;           // elements between two frame rows of M / U inside a group
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
     const double dual = st.dual_norm;
@@ -350,8 +351,12 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
         if (tile >= ntiles) continue;
         const unsigned p = (unsigned)(tile * 16 + pl);
         const bool pvalid = p < P32;
-        const unsigned vo8 = pvalid ? ((unsigned)fr0 * ps32 + p) * 8u : kOob;     // f64 planes
-        const unsigned vo2 = pvalid ? ((unsigned)fr0 * ps32 + p) * 2u : kOob;     // binary16 planes
+        // M and U are private to this kernel and laid out group-major, [group of 128 pixels][frame][128 pixels]:
+        // the 64 rows a workgroup streams together sit in one 64 KB (16 KB) block instead of 64 distant planes
+        // (-3 % per launch against frame-major planes, same box)
+        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)b.fpad * 128u + (unsigned)fr0 * 128u + ((unsigned)tile & 7u) * 16u + (unsigned)pl;
+        const unsigned vo8 = pvalid ? ge * 8u : kOob;                             // f64 state
+        const unsigned vo2 = pvalid ? ge * 2u : kOob;                             // binary16 copy of Y/mu
         const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
         const unsigned vo1s = ws ? vo1 : kOob;
         const unsigned vo2r = ru ? vo2 : kOob, vo2w = wu ? vo2 : kOob;
@@ -363,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
             const bool fvalid = FULL || 4 * t < flim;
             xi[t] = buf_ld8(rX, fvalid ? vo1 : kOob, (unsigned)(4 * t) * P32);
             if (MODE == 2) {
-                mv[t] = buf_ld64(rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
-                uf[t] = buf_ld16h(rU, fvalid ? (t == 0 ? vo2 : vo2r) : kOob, (unsigned)(4 * t) * ps32 * 2u);
+                mv[t] = buf_ld64(rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ROWSTEP * 8u);
+                uf[t] = buf_ld16h(rU, fvalid ? (t == 0 ? vo2 : vo2r) : kOob, (unsigned)(4 * t) * ROWSTEP * 2u);
             }
         }
         if (MODE == 1) {
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
                     sT[(4 * t + fr0) * TP + pl] = m2;
                     const bool fvalid = FULL || 4 * t < flim;
                     if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
-                        buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ps32 * 8u);
-                        buf_st16h((float)u, rU, fvalid ? (t == 0 ? vo2 : vo2w) : kOob, (unsigned)(4 * t) * ps32 * 2u);
+                        buf_st64(m2, rM, fvalid ? vo8 : kOob, (unsigned)(4 * t) * ROWSTEP * 8u);
+                        buf_st16h((float)u, rU, fvalid ? (t == 0 ? vo2 : vo2w) : kOob, (unsigned)(4 * t) * ROWSTEP * 2u);
                     }
                     buf_st8((int)sparse_u8b(e2), rS, fvalid ? vo1s : kOob, (unsigned)(4 * t) * P32);
                 }

@@ -257,7 +257,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (ngroups > nwin) ngroups = nwin;
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
     b.nred = b.nblk > 16 ? 1 : b.nblk;      // many slabs: reduce them chip-wide first (k_gram_reduce)
-    b.pstride = ((int64_t)P + 15) & ~(int64_t)15;
+    b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
     b.fpad = (n + 15) & ~15;
     ctx->pstride = b.pstride;
     ctx->fpad = b.fpad;
@@ -479,7 +479,7 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
         rc = rc ? rc : need(ctx, SL_S, elems, &p);
         rc = rc ? rc : need(ctx, SL_OPEN, elems, &p);
         rc = rc ? rc : need(ctx, SL_LAB8, elems, &p);
-        const size_t felems = (size_t)max_windows * ((max_n + 15) & ~15) * (((size_t)max_Hc * max_Wc + 15) & ~(size_t)15);
+        const size_t felems = (size_t)max_windows * ((max_n + 15) & ~15) * (((size_t)max_Hc * max_Wc + 127) & ~(size_t)127);
         rc = rc ? rc : need(ctx, SL_A, felems * 8, &p);
         rc = rc ? rc : need(ctx, SL_Y, felems * 8, &p);
         if (rc) { g_create_error = ctx->err; swk_ctx_destroy(ctx); return rc; }
