@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
     const bool ru = st.ru != 0, wu = st.wu != 0; // all of U read (full ||Z||) / written in this pass; else frames 0..3 only
     const int n = b.n, P = b.P;
     const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
-    constexpr unsigned ROWSTEP = 128u;           // elements between two frame rows of M / U inside a group
+    constexpr unsigned ROWSTEP = 128u;           // (4 t) * ROWSTEP = t * 512 elements: one chunk of M / U per k-step
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
     const double dual = st.dual_norm;
@@ -351,10 +351,11 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v3(IalmBuffers b, int sel)
         if (tile >= ntiles) continue;
         const unsigned p = (unsigned)(tile * 16 + pl);
         const bool pvalid = p < P32;
-        // M and U are private to this kernel and laid out group-major, [group of 128 pixels][frame][128 pixels]:
-        // the 64 rows a workgroup streams together sit in one 64 KB (16 KB) block instead of 64 distant planes
-        // (-3 % per launch against frame-major planes, same box)
-        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)b.fpad * 128u + (unsigned)fr0 * 128u + ((unsigned)tile & 7u) * 16u + (unsigned)pl;
+        // M and U are private to this kernel.  Layout [group of 128 pixels][k-step t][tile 0..7][frame 4t + 0..3][16 px]:
+        // what one wave instruction touches (4 frame rows x 16 pixels of one k-step) is ONE contiguous piece -- 512 B
+        // of M, a full 128-B line of U -- and the 64 rows a workgroup streams together form one 64 KB (16 KB) block.
+        // Against frame-major planes (four lines 700 KB apart per instruction, 32-byte pieces of U): -6 % per launch.
+        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)b.fpad * 128u + ((unsigned)tile & 7u) * 64u + (unsigned)fr0 * 16u + (unsigned)pl;
         const unsigned vo8 = pvalid ? ge * 8u : kOob;                             // f64 state
         const unsigned vo2 = pvalid ? ge * 2u : kOob;                             // binary16 copy of Y/mu
         const unsigned vo1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;             // u8 planes
