@@ -1,6 +1,7 @@
 // Memory-shape probe for the M-state IALM pass (diagnostic, not part of the library): moves exactly the pass's
 // bytes (X u8 + M f64 + U f16 read, M f64 + U f16 + S u8 written in place) with no arithmetic, in two shapes:
-//   shape 0: as k_ialm_pass_v3 -- per 16-pixel tile, every plane as 16-pixel row segments (X/S: 16 B, U: 32 B, M: 128 B)
+//   shape 0: as k_ialm_pass_v3 -- X/S frame-major planes (16-byte row segments), M/U in the pass's chunk layout
+//            (one contiguous 512-B / 128-B piece per wave instruction)
 //   shape 1: X and S as one dword per lane over a 64-pixel super-tile (64-B row segments), U and M per tile as before
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/pass_probe tools/pass_probe.hip
 #include <hip/hip_runtime.h>
@@ -14,7 +15,8 @@ __global__ __launch_bounds__(256, 2) void k_probe(const uint8_t *__restrict__ X,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, fr0 = lane >> 4;
     const size_t wofs = (size_t)blockIdx.y * 64 * P;
-    X += wofs; S += wofs; M += wofs; U += wofs;
+    const size_t wofs_c = (size_t)blockIdx.y * 64 * ((size_t)(P + 127) / 128 * 128);      // chunk layout: whole groups
+    X += wofs; S += wofs; M += (SHAPE == 0 ? wofs_c : wofs); U += (SHAPE == 0 ? wofs_c : wofs);
     if (SHAPE == 0) {
         const int nlg = (ntiles + 7) >> 3;
         for (int lg = blockIdx.x; lg < nlg; lg += gridDim.x)
@@ -22,13 +24,15 @@ __global__ __launch_bounds__(256, 2) void k_probe(const uint8_t *__restrict__ X,
                 const int tile = lg * 8 + wave * 2 + h;
                 if (tile >= ntiles) continue;
                 const size_t o = (size_t)fr0 * P + tile * 16 + pl;
+                // M and U as the pass keeps them: [group of 128 px][k-step t][tile][frame 4t + 0..3][16 px]
+                const size_t oc = (size_t)(tile >> 3) * 64 * 128 + (size_t)(tile & 7) * 64 + fr0 * 16 + pl;
                 int x[16]; double m[16]; unsigned short u[16];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) { x[t] = X[o + (size_t)4 * t * P]; m[t] = M[o + (size_t)4 * t * P]; u[t] = U[o + (size_t)4 * t * P]; }
+                for (int t = 0; t < 16; ++t) { x[t] = X[o + (size_t)4 * t * P]; m[t] = M[oc + (size_t)t * 512]; u[t] = U[oc + (size_t)t * 512]; }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    M[o + (size_t)4 * t * P] = m[t] + (double)u[t];
-                    U[o + (size_t)4 * t * P] = (unsigned short)(u[t] + x[t]);
+                    M[oc + (size_t)t * 512] = m[t] + (double)u[t];
+                    U[oc + (size_t)t * 512] = (unsigned short)(u[t] + x[t]);
                     S[o + (size_t)4 * t * P] = (uint8_t)(x[t] + 1);
                 }
             }
@@ -66,8 +70,8 @@ int main()
     const int W = 128, P = 89888;           // P % 64 == 32: the last super-tile is half full (bytes past P land in the next plane: harmless here)
     const size_t elems = (size_t)W * 64 * P;
     uint8_t *X, *S; double *M; unsigned short *U;
-    if (hipMalloc(&X, elems + 256) != hipSuccess || hipMalloc(&S, elems + 256) != hipSuccess || hipMalloc(&M, elems * 8) != hipSuccess ||
-        hipMalloc(&U, elems * 2) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    if (hipMalloc(&X, elems + 256) != hipSuccess || hipMalloc(&S, elems + 256) != hipSuccess || hipMalloc(&M, (size_t)W * 64 * ((P + 127) / 128 * 128) * 8) != hipSuccess ||
+        hipMalloc(&U, (size_t)W * 64 * ((P + 127) / 128 * 128) * 2) != hipSuccess) { printf("alloc failed\n"); return 1; }
     (void)hipMemset(X, 1, elems); (void)hipMemset(S, 0, elems); (void)hipMemset(M, 0, elems * 8); (void)hipMemset(U, 0, elems * 2);
     const int ntiles = (P + 15) / 16;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
