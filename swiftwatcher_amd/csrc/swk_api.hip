@@ -256,7 +256,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (ngroups > kMaxGroups) ngroups = kMaxGroups;
     if (ngroups > nwin) ngroups = nwin;
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
-    b.nred = b.nblk > 16 ? 1 : b.nblk;      // many slabs: reduce them chip-wide first (k_gram_reduce)
+    b.nred = b.nblk > 4 ? 1 : b.nblk;       // several slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
     b.fpad = (n + 15) & ~15;
     ctx->pstride = b.pstride;
@@ -346,7 +346,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
         { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]);
-          if (grp[g].b.nblk > 16) launch_gram_reduce(ctx->gstream[g], grp[g].b);
+          if (grp[g].b.nblk > 4) launch_gram_reduce(ctx->gstream[g], grp[g].b);
           launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], ctx->gstream[g]));
     }
@@ -370,7 +370,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             hipStream_t gs = ctx->gstream[g];
             HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
             { Timed t(ctx, SWK_K_IALM_SMALL, gs);
-              if (gr.b.nblk > 16) launch_gram_reduce(gs, gr.b);
+              if (gr.b.nblk > 4) launch_gram_reduce(gs, gr.b);
               launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
             HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
             if (k >= check_from) {
