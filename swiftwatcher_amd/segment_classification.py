@@ -12,6 +12,8 @@ Differences from the reference, all deliberate:
   * by default only the part of each feature map the 24x24 patch can influence is evaluated
     (CroppedSqueezeNet10, 4.7x fewer MACs, same arithmetic per output); cropped=False runs the full network.
 """
+import ctypes
+
 import numpy as np
 import torch
 from torch import nn
@@ -231,7 +233,7 @@ class CroppedSqueezeNet10:
         (swk_nhwc_maxpool3s2), both on PyTorch's current stream.  Same float32 operations per element as above."""
         from . import _lib
         lib = _lib.load()
-        stream = ctypes_void_p(torch.cuda.current_stream(tiles.device).cuda_stream)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(tiles.device).cuda_stream)
         m = self.model
         conv2d = torch.nn.functional.conv2d
         k = tiles.shape[0]
@@ -302,11 +304,6 @@ class CroppedSqueezeNet10:
                 aux["pool_out"].append(buf(tile.shape[1], (tile.shape[2] - 3) // 2 + 1))
         self._aux, self._aux_cap = aux, batch
         return aux
-
-
-def ctypes_void_p(v):
-    import ctypes
-    return ctypes.c_void_p(v)
 
 
 def setup_model(num_classes):
