@@ -57,3 +57,23 @@ class ArrayReader:
             f, k, t = self.get_frame()
             frames.append(f); numbers.append(k); stamps.append(t)
         return frames, numbers, stamps
+
+
+class RawFileReader(ArrayReader):
+    """ArrayReader over a file of decoded frames that is memory-mapped instead of loaded (SURVEY section 8f rank 2:
+    "pre-extracted streams"; the image has no video codec): either a .npy array of shape (frames, H, W, 3) uint8 or a
+    headerless raw file of consecutive H x W x 3 BGR frames (frame_shape required).  Frames are handed out as views
+    of the mapping, so only the pages the ROI crop touches are ever read from disk."""
+
+    def __init__(self, path, frame_shape=None, fps=30.0, start=0, end=0):
+        if str(path).endswith(".npy"):
+            frames = np.load(path, mmap_mode="r")
+        else:
+            if frame_shape is None:
+                raise ValueError("a raw frame file needs frame_shape=(H, W, 3)")
+            frames = np.memmap(path, dtype=np.uint8, mode="r")
+            per = int(np.prod(frame_shape))
+            frames = frames[:frames.size // per * per].reshape((-1,) + tuple(frame_shape))
+        if frames.dtype != np.uint8 or frames.ndim != 4:
+            raise ValueError("expected uint8 frames of shape (frames, H, W, channels)")
+        ArrayReader.__init__(self, frames, fps=fps, start=start, end=end, filepath=path)

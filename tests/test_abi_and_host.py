@@ -132,3 +132,26 @@ def test_array_reader_mirrors_framereader_bookkeeping():
     assert not got[6].any() and got[6].shape == (4, 5, 3) and stamps[6] == "00:00:00.000"
     assert (stamps[3] - stamps[0]).total_seconds() == pytest.approx(0.3)
     assert r.frames_read == 5
+
+
+def test_raw_file_reader_has_the_frame_reader_semantics(tmp_path):
+    """Memory-mapped frame files behind the reference FrameReader's bookkeeping (io_video.py:13-82): frames, numbers,
+    the re-delivered last frame, null frames past the end."""
+    from swiftwatcher_amd.io_frames import ArrayReader, RawFileReader
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(5, 6, 8, 3), dtype=np.uint8)
+    raw = tmp_path / "clip.bgr"
+    frames.tofile(raw)
+    npy = tmp_path / "clip.npy"
+    np.save(npy, frames)
+    ref = ArrayReader(list(frames))
+    want = ref.get_n_frames(8)
+    for reader in (RawFileReader(str(raw), frame_shape=(6, 8, 3)), RawFileReader(str(npy))):
+        assert reader.total_frames == 5
+        got = reader.get_n_frames(8)
+        assert got[1] == want[1] == [0, 1, 2, 3, 4, 5, -1, -1]
+        for a, b in zip(got[0], want[0]):
+            np.testing.assert_array_equal(a, b)
+        assert reader.read_errors == ref.read_errors == 1
+    with pytest.raises(ValueError):
+        RawFileReader(str(raw))
