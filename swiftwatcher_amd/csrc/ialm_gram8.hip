@@ -17,7 +17,7 @@ namespace swk {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int NB>
+template <int NB, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gram_u8(IalmBuffers b)
 {
     constexpr int NPAD = 16 * NB, NPAIR = NB * (NB + 1) / 2;
@@ -28,7 +28,13 @@ __global__ __launch_bounds__(256) void k_gram_u8(IalmBuffers b)
     const int w = blockIdx.y, n = b.n, P = b.P;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, g = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    // ALIGNED: one descriptor per window (its range check zeroes what lies past the window).  Otherwise the dword
+    // loads are relative to the 4-byte aligned start of the whole batch and carry the window offset themselves.
+    const unsigned wbase = ALIGNED ? 0u : (unsigned)w * (unsigned)n * (unsigned)P;
+    const __amdgpu_buffer_rsrc_t rX = ALIGNED
+        ? __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void *)b.X, 0, (int)(((int64_t)b.nwin * n * P + 3) & ~3ll), 0x00020000);   // whole dwords:
+    // the range check drops a dword that is only partly inside; X lives in the library's own, padded allocation
     v4i acc[NPAIR];
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) acc[i] = v4i{0, 0, 0, 0};
@@ -49,8 +55,20 @@ __global__ __launch_bounds__(256) void k_gram_u8(IalmBuffers b)
             const int frame = fb * 16 + fi;
             // past the last frame or the last pixel of the window the range check returns zeros; a row's last 16
             // pixels may run into the next row, which the tail mask below removes
-            const unsigned off = (frame < n && p0 < P) ? (unsigned)frame * (unsigned)P + (unsigned)p0 : 0x80000000u;
-            a[fb] = __builtin_amdgcn_raw_buffer_load_b128(rX, off, 0, 0);
+            const bool ok = frame < n && p0 < P;
+            const unsigned off = wbase + (unsigned)frame * (unsigned)P + (unsigned)p0;
+            if (ALIGNED) {
+                a[fb] = __builtin_amdgcn_raw_buffer_load_b128(rX, ok ? off : 0x80000000u, 0, 0);
+            } else {
+                // rows that do not start on a 16-byte boundary (e.g. 214 x 107, 850 x 425): five aligned dwords and
+                // a byte funnel shift per lane
+                const unsigned base = ok ? (off & ~3u) : 0x80000000u, sh = off & 3u;
+                unsigned d[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) d[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rX, base, 4 * q, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[fb][q] = (int)__builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            }
         }
         const int left = P - p0;                       // valid pixels among this lane's 16
         cnt += (P - c * 64 < 64 ? P - c * 64 : 64);
@@ -119,21 +137,29 @@ __global__ __launch_bounds__(256) void k_gram_u8(IalmBuffers b)
 
 bool gram_u8_supported(const IalmBuffers &b)
 {
-    // 16-byte loads: rows must start 16-byte aligned; i32 accumulators: at most 2^16 pixels per wave
-    if ((b.P & 15) || (((uintptr_t)b.X) & 15)) return false;
+    // i32 accumulators: at most 2^16 pixels per wave; dword loads: the window base must be 4-byte aligned
+    if ((((uintptr_t)b.X) & 3) || (int64_t)b.nwin * b.n * b.P >= (1ll << 31)) return false;
     const long long per_wave = ((long long)b.P + 4ll * b.nblk - 1) / (4ll * b.nblk) + 64;
     return per_wave <= 65536;
 }
 
+template <int NB>
+static void launch_gram_nb(hipStream_t s, const IalmBuffers &b)
+{
+    const dim3 grid(b.nblk, b.nwin), block(256);
+    // 16-byte loads need every frame row of every window on a 16-byte boundary
+    const bool aligned = (b.P & 15) == 0 && (((uintptr_t)b.X) & 15) == 0;
+    if (aligned) hipLaunchKernelGGL((k_gram_u8<NB, true>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((k_gram_u8<NB, false>), grid, block, 0, s, b);
+}
+
 void launch_gram_u8(hipStream_t s, const IalmBuffers &b)
 {
-    const int nb = (b.n + 15) / 16;
-    const dim3 grid(b.nblk, b.nwin), block(256);
-    switch (nb) {
-    case 1: hipLaunchKernelGGL(k_gram_u8<1>, grid, block, 0, s, b); break;
-    case 2: hipLaunchKernelGGL(k_gram_u8<2>, grid, block, 0, s, b); break;
-    case 3: hipLaunchKernelGGL(k_gram_u8<3>, grid, block, 0, s, b); break;
-    default: hipLaunchKernelGGL(k_gram_u8<4>, grid, block, 0, s, b); break;
+    switch ((b.n + 15) / 16) {
+    case 1: launch_gram_nb<1>(s, b); break;
+    case 2: launch_gram_nb<2>(s, b); break;
+    case 3: launch_gram_nb<3>(s, b); break;
+    default: launch_gram_nb<4>(s, b); break;
     }
 }
 

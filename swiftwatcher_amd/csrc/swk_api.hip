@@ -475,7 +475,7 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
         const size_t elems = (size_t)max_windows * max_n * max_Hc * max_Wc;
         void *p;
         int rc = 0;
-        rc = rc ? rc : need(ctx, SL_X, elems, &p);
+        rc = rc ? rc : need(ctx, SL_X, elems + 4, &p);
         rc = rc ? rc : need(ctx, SL_S, elems, &p);
         rc = rc ? rc : need(ctx, SL_OPEN, elems, &p);
         rc = rc ? rc : need(ctx, SL_LAB8, elems, &p);
@@ -644,7 +644,10 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
     }
     // ---- stage buffers (caller's device buffers are written in place) ----
     uint8_t *dX, *dS, *dBil = nullptr, *dThr = nullptr, *dOpen, *dLab;
-    if (dev_out && out->gray) dX = out->gray; else NEED(ctx, SL_X, plane, dX);
+    // (a gray plane whose size is not a whole number of dwords stays in the library's padded buffer: k_gram_u8 reads
+    // it in dwords; the caller's copy is made at the end)
+    const bool gray_in_place = dev_out && out->gray && (plane & 3) == 0;
+    if (gray_in_place) dX = out->gray; else NEED(ctx, SL_X, plane + 4, dX);
     if (dev_out && out->rpca) dS = out->rpca; else NEED(ctx, SL_S, plane, dS);
     if (out->bilateral) { if (dev_out) dBil = out->bilateral; else NEED(ctx, SL_BIL, plane, dBil); }
     if (out->thresh) { if (dev_out) dThr = out->thresh; else NEED(ctx, SL_THR, plane, dThr); }
@@ -701,6 +704,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
             if (!dev_out) { rc = copy_out(ctx, dst, pn, elems * 8, out->mem); if (rc) return rc; HIPCHK(ctx, hipStreamSynchronize(s)); }
         }
     }
+    if (dev_out && out->gray && !gray_in_place) { rc = copy_out(ctx, out->gray, dX, plane, out->mem); if (rc) return rc; }
     if (!dev_out) {
         Timed t(ctx, SWK_K_COPY);
         rc = copy_out(ctx, out->gray, dX, plane, out->mem); if (rc) return rc;
@@ -737,7 +741,7 @@ int32_t swk_ialm(swk_ctx *ctx, const uint8_t *planes, int32_t n, int32_t P, doub
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t elems = (size_t)n * P;
     uint8_t *dX, *dS;
-    NEED(ctx, SL_X, elems, dX);
+    NEED(ctx, SL_X, elems + 4, dX);
     NEED(ctx, SL_S, elems, dS);
     HIPCHK(ctx, hipMemcpyAsync(dX, planes, elems, hipMemcpyHostToDevice, ctx->stream));
     int rc = run_ialm(ctx, dX, 1, n, P, lmbda, tol, maxiter, A != nullptr, E != nullptr, dS, iters, nullptr);

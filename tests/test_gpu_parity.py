@@ -236,6 +236,19 @@ def test_integer_start_matches_f64_start():
         np.testing.assert_array_equal(a["rpca"], b["rpca"])
     np.testing.assert_array_equal(out[0]["labels"], out[2]["labels"])
     assert out[0]["segs"].tobytes() == out[2]["segs"].tobytes()
+    # ROI rows that do not start on 16-byte boundaries (P1 = 214 x 107, and 21 frames so that odd windows start on a
+    # 2-byte boundary): the unaligned variant of the integer kernel against the f64 start
+    roi = np.concatenate([synthetic.roi_window(120 + w, 21, 212, 427, birds=6) for w in range(3)] )
+    roi64 = np.concatenate([synthetic.roi_window(130 + w, 64, 107, 214, birds=6, bird_len=(10, 15), bird_wid=(4, 7)) for w in range(2)])
+    res = []
+    for on in (1, 0):
+        c = _lib.Context(0)
+        c.set_integer_start(on)
+        res.append((c.batch_run(roi, 3, 21, stages=("rpca",)), c.batch_run(roi64, 2, 64, stages=("rpca",))))
+        c.close()
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        np.testing.assert_array_equal(a["rpca"], b["rpca"])
 
 
 def test_sparse_store_speculation_never_changes_results(orc):
