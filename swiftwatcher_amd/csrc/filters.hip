@@ -70,6 +70,41 @@ __global__ __launch_bounds__(256) void k_gray4(const uint8_t *__restrict__ frame
     *(uint32_t *)(out + ((int64_t)f * H + r) * W + c) = packed;
 }
 
+// Any width: quads per row rounded up, the last one partial; the store is as wide as the output address allows
+// (rows of a 214- or 850-pixel ROI start on alternating 4- and 2-byte boundaries).
+__global__ __launch_bounds__(256) void k_gray4g(const uint8_t *__restrict__ frames, int64_t frame_stride, int64_t row_stride,
+                                                int x0, int y0, int H, int W, int mode, uint8_t *__restrict__ out)
+{
+    const int f = blockIdx.y;
+    const int wq = (W + 3) >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * wq) return;
+    const int r = idx / wq, c = (idx - r * wq) << 2;
+    const int npx = W - c < 4 ? W - c : 4;
+    const uint8_t *src = frames + (int64_t)f * frame_stride + (int64_t)(y0 + r) * row_stride + (int64_t)(x0 + c) * 3;
+    uint32_t b[12];
+    if (npx == 4 && ((uintptr_t)src & 3) == 0) {
+        const uint32_t *s32 = (const uint32_t *)src;
+        const uint32_t w0 = s32[0], w1 = s32[1], w2 = s32[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 255u; b[4 + k] = (w1 >> (8 * k)) & 255u; b[8 + k] = (w2 >> (8 * k)) & 255u; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = k < 3 * npx ? src[k] : 0u;
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t y = mode == SWK_GRAY_Q14 ? (b[3 * k] * 1868u + b[3 * k + 1] * 9617u + b[3 * k + 2] * 4899u + (1u << 13)) >> 14
+                                                : (b[3 * k] * 3735u + b[3 * k + 1] * 19235u + b[3 * k + 2] * 9798u + (1u << 14)) >> 15;
+        packed |= y << (8 * k);
+    }
+    uint8_t *dst = out + ((int64_t)f * H + r) * W + c;
+    if (npx == 4 && ((uintptr_t)dst & 3) == 0) *(uint32_t *)dst = packed;
+    else if (npx == 4 && ((uintptr_t)dst & 1) == 0) { ((uint16_t *)dst)[0] = (uint16_t)packed; ((uint16_t *)dst)[1] = (uint16_t)(packed >> 16); }
+    else for (int k = 0; k < npx; ++k) dst[k] = (uint8_t)(packed >> (8 * k));
+}
+
 void launch_gray(hipStream_t s, const uint8_t *frames, int channels, int64_t frame_stride, int64_t row_stride,
                  int x0, int y0, int F, int H, int W, int gray_mode, uint8_t *out)
 {
@@ -83,7 +118,17 @@ void launch_gray(hipStream_t s, const uint8_t *frames, int channels, int64_t fra
         }
         return;
     }
-    // grid.z is limited to 65535: split the frame range
+    if (channels == 3) {
+        const int groups = H * ((W + 3) >> 2);
+        for (int f0 = 0; f0 < F; f0 += 32768) {
+            const int fc = F - f0 < 32768 ? F - f0 : 32768;
+            hipLaunchKernelGGL(k_gray4g, dim3((groups + 255) / 256, fc), dim3(256), 0, s,
+                               frames + (int64_t)f0 * frame_stride, frame_stride, row_stride, x0, y0, H, W, gray_mode,
+                               out + (int64_t)f0 * H * W);
+        }
+        return;
+    }
+    // single-channel input (passes through): grid.z is limited to 65535, split the frame range
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
         hipLaunchKernelGGL(k_gray, dim3((W + 255) / 256, H, fc), dim3(256), 0, s,
