@@ -307,40 +307,32 @@ __global__ __launch_bounds__(256) void k_filter_fused(const uint8_t *__restrict_
     __syncthreads();
     // ---- source tile: rows r0-5 .. r0+36, columns c0-8 .. c0+71; its nonzero pixels also go into row bit masks ----
     int seen = 0;                                  // this thread loaded a nonzero pixel
-    const bool inside = r0 - kHalo >= 0 && r0 + kTH + kHalo <= H && c0 - kSX >= 0 && c0 - kSX + kSP <= W;
-    const bool interior = inside && (W & 3) == 0 && (((uintptr_t)img) & 3) == 0;
-    if (inside && !interior && (W & 1) == 0 && (((uintptr_t)img) & 1) == 0) {
-        // window inside the image but rows only 2-byte aligned (e.g. W = 214): 16-bit loads, no border arithmetic
-        for (int i = tid; i < kSH * (kSP / 2); i += 256) {
-            const int sr = i / (kSP / 2), q = i - sr * (kSP / 2);
-            const uint32_t v = *(const uint16_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 2 * q);
-            ((uint16_t *)s_src)[i] = (uint16_t)v;
-            if (v) {
-                seen = 1;
-                const uint32_t two = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u);
-                atomicOr(&s_nz[sr * 3 + (q >> 4)], two << (2 * (q & 15)));
-            }
+    // One dword (4 columns) per step.  Rows and columns outside the image are BORDER_REFLECT_101 copies (the taps of
+    // in-image pixels reach up to kR beyond it); cells farther out are never consumed.  Inside the image the load is
+    // as wide as the address allows (rows of a 214- or 850-pixel ROI start on alternating 4- and 2-byte boundaries).
+    for (int i = tid; i < kSH * (kSP / 4); i += 256) {
+        const int sr = i / (kSP / 4), q = i - sr * (kSP / 4);
+        int rr = r0 - kHalo + sr;
+        if (rr < 0 || rr >= H) rr = reflect101(rr, H);
+        const int c = c0 - kSX + 4 * q;
+        const uint8_t *rowp = img + (int64_t)rr * W;
+        uint32_t v;
+        if (c >= 0 && c + 3 < W) {
+            const uint8_t *pp = rowp + c;
+            if (((uintptr_t)pp & 3) == 0) v = *(const uint32_t *)pp;
+            else if (((uintptr_t)pp & 1) == 0) v = (uint32_t)((const uint16_t *)pp)[0] | ((uint32_t)((const uint16_t *)pp)[1] << 16);
+            else v = (uint32_t)pp[0] | ((uint32_t)pp[1] << 8) | ((uint32_t)pp[2] << 16) | ((uint32_t)pp[3] << 24);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v |= (uint32_t)rowp[reflect101(c + k, W)] << (8 * k);
         }
-    } else if (interior) {
-        for (int i = tid; i < kSH * (kSP / 4); i += 256) {
-            const int sr = i / (kSP / 4), q = i - sr * (kSP / 4);
-            const uint32_t v = *(const uint32_t *)(img + (int64_t)(r0 - kHalo + sr) * W + (c0 - kSX) + 4 * q);
-            ((uint32_t *)s_src)[i] = v;
-            if (v) {
-                seen = 1;
-                const uint32_t nib = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) |
-                                     ((v & 0xff000000u) ? 8u : 0u);
-                atomicOr(&s_nz[sr * 3 + (q >> 3)], nib << (4 * (q & 7)));
-            }
-        }
-    } else {
-        for (int i = tid; i < kSH * kSP; i += 256) {
-            const int sr = i / kSP, sc = i - sr * kSP;
-            // taps of in-image pixels reach outside the image by up to kR and use BORDER_REFLECT_101 there, so every
-            // cell holds img[reflect101(coordinate)]; cells far outside the image are never consumed
-            const uint8_t v = img[reflect101(r0 - kHalo + sr, H) * W + reflect101(c0 - kSX + sc, W)];
-            s_src[i] = v;
-            if (v) { seen = 1; atomicOr(&s_nz[sr * 3 + (sc >> 5)], 1u << (sc & 31)); }
+        ((uint32_t *)s_src)[i] = v;
+        if (v) {
+            seen = 1;
+            const uint32_t nib = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) |
+                                 ((v & 0xff000000u) ? 8u : 0u);
+            atomicOr(&s_nz[sr * 3 + (q >> 3)], nib << (4 * (q & 7)));
         }
     }
     // empty source window: every stage outputs zero, which the (cleared) buffers already hold
