@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the segment hot path (BASELINE.json configs[1]):
+"""Benchmark of the segment + classify hot path (BASELINE.json metric, workload = configs[1]'s stream):
 
     synthetic 1080p ROI stream (424x212 crop of a 340-px chimney), frame-batch = 64
-    (FrameQueue(queue_size=64)), image_filtering HIP kernels, one MI355X per rank.
+    (FrameQueue(queue_size=64)), image_filtering HIP kernels + the segment_classification CNN
+    (SqueezeNet-1.0 on PyTorch-ROCm, fp32, eval mode), one MI355X per rank.
 
-A "step" is one swk_batch_run over `--windows` independent 64-frame RPCA windows whose BGR ROI
-frames are already resident in HBM; products (u8 label planes, per-frame segment records,
-iteration counts) stay in HBM.  value = ROI frames/s over all ranks.
+A "step" is one pass of the path over `--windows` independent 64-frame RPCA windows whose BGR ROI frames are already
+resident in HBM: swk_batch_run (gray, RPCA/IALM, bilateral, threshold, opening, CCL, region properties), then every
+segment of every frame through the classifier (inputs cut on the device by swk_segment_inputs) and the
+keep-if-argmax==1 rule (segment_classification.py:36-39) reduced to kept segments per frame -- the reference's
+__main__.py:77-85 for the whole batch.  value = ROI frames/s over all ranks.
+
+After the headline loop a second timed loop runs the image_filtering part alone (BASELINE configs[1] as worded:
+"image_filtering HIP kernels") and reports it, with the streaming kernel's roofline, under "segment_only".
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
+Prints ONE JSON line on rank 0 (contract fields + "roofline" + "roofline_cnn" + "segment_only" + "cpu_baseline").
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,7 +31,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# algorithmic bytes per matrix element and IALM iteration of the streaming pass (DESIGN.md section 4):
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* at the f32 vector rate (155 measured)
+# algorithmic bytes per matrix element and IALM iteration of the streaming pass (DESIGN.md section 5):
 #   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
 #   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 written = 21; first = 11;
 #                                              the sparse u8 image is needed once per window (+1 B per element, booked
@@ -39,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=128, help="64-frame windows per step per GPU")
+    ap.add_argument("--windows", type=int, default=128, help="windows per step per GPU")
     ap.add_argument("--n", type=int, default=64, help="frames per window (queue_size)")
     ap.add_argument("--size", default="P2", choices=["P1", "P2", "P3"])
     ap.add_argument("--integer-start", type=int, default=None, help="A/B: swk_set_integer_start (0 = f64 start pass)")
@@ -47,25 +53,30 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=None, help="experiments: IALM iteration cap (reference: 100)")
     ap.add_argument("--sparse-spec", type=float, default=None, help="A/B: swk_set_sparse_speculation factor (0 = stores in every pass)")
     ap.add_argument("--norm-spec", type=float, default=None, help="A/B: swk_set_norm_speculation factor (0 = norm in every pass)")
-    ap.add_argument("--classify", action="store_true",
-                    help="also classify every segment inside the timed step (SqueezeNet-1.0 on PyTorch-ROCm, random-init "
-                         "weights, inputs cut on the device by swk_segment_inputs): BASELINE config 3 without the tracker")
+    ap.add_argument("--classify", action="store_true", help="(default) kept for compatibility: the classifier is part of the step")
+    ap.add_argument("--no-classify", action="store_true",
+                    help="time the image_filtering part only (the headline metric then reads 'segment'); for kernel A/Bs")
+    ap.add_argument("--full-network", action="store_true", help="A/B: the full 224x224 forward instead of the receptive-field cropped one")
+    ap.add_argument("--cls-batch", type=int, default=2048, help="segments per classifier forward")
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
     ap.add_argument("--eig-method", type=int, default=0, help="0 Newton-Schulz (MFMA), 1 Jacobi")
     ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=3, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
-    ap.add_argument("--host-input", action="store_true", help="also time a step fed from host memory (PCIe inclusive)")
+    ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
+    ap.add_argument("--host-input", action="store_true", help="also time a segment step fed from host memory (PCIe inclusive)")
     return ap.parse_args()
 
 
-def cpu_baseline(n, Hc, Wc, nwin, seed=424242):
-    """The CPU oracle (numpy + C restatement of the reference path) on a bounded sample of the same
-    workload.  kind = "port": the reference's own cv2 stages cannot run anywhere in this image."""
+def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
+    """The CPU oracle (numpy + C restatement of the reference path, + the batch-1 CPU classifier the reference runs)
+    on a bounded sample of the same workload.  kind = "port": the reference's own cv2 / torchvision stages cannot run
+    anywhere in this image."""
     import numpy as np
+    import torch
     from swiftwatcher_amd import synthetic
     from oracle import reference_path as orc
+    from oracle import classifier_ref
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
@@ -73,14 +84,35 @@ def cpu_baseline(n, Hc, Wc, nwin, seed=424242):
         threads = os.cpu_count() or 1
     rois = [synthetic.roi_window(seed + w, n, Hc, Wc) for w in range(nwin)]
     t0 = time.perf_counter()
-    nseg = 0
-    for roi in rois:
-        res = orc.window(roi)
-        nseg += sum(len(s) for s in res["segments"])
-    dt = time.perf_counter() - t0
-    return dict(value=round(nwin * n / dt, 3), unit="frames/s", cores=int(threads), kind="port",
-                sample="%d window(s) of %d frames at %dx%d ROI: numpy/LAPACK SVD IALM (BLAS threads=%d) + "
-                       "single-threaded C for the byte stages, %.1f s" % (nwin, n, Wc, Hc, threads, dt))
+    results = [orc.window(roi) for roi in rois]
+    t_seg = time.perf_counter() - t0
+    nseg = sum(len(s) for res in results for s in res["segments"])
+    out = dict(unit="frames/s", cores=int(threads), kind="port")
+    t_cls = 0.0
+    if classify:
+        # every segment of the sample's FIRST window through the batch-1 classifier (segment_classification.py:29-36),
+        # scaled to all of the sample's segments
+        crop_region = [(0, 0), (Wc, Hc)]
+        crops = []
+        for pos, segs in enumerate(results[0]["segments"]):
+            for s in segs:
+                r0, c0, r1, c1 = orc.segment_crop_box(s["bbox"], (24, 24), crop_region)
+                crops.append(rois[0][pos][max(r0, 0):max(r1, 0), max(c0, 0):max(c1, 0)])
+        sd = classifier_ref.random_state_dict(0)
+        t1 = time.perf_counter()
+        classifier_ref.classify(sd, crops)
+        per_seg = (time.perf_counter() - t1) / max(len(crops), 1)
+        t_cls = per_seg * nseg
+        out["classify_ms_per_segment"] = round(per_seg * 1e3, 3)
+        out["torch_threads"] = int(torch.get_num_threads())
+    out["value"] = round(nwin * n / (t_seg + t_cls), 3)
+    out["segment_only_value"] = round(nwin * n / t_seg, 3)
+    out["sample"] = ("%d window(s) of %d frames at %dx%d ROI, %d segments: numpy/LAPACK SVD IALM (BLAS threads=%d) + "
+                     "single-threaded C for the byte stages, %.1f s%s"
+                     % (nwin, n, Wc, Hc, nseg, threads, t_seg,
+                        "; batch-1 torch CPU SqueezeNet-1.0 (full 224x224, as the reference) timed on the first window's "
+                        "segments and scaled to all of them, %.1f s" % t_cls if classify else ""))
+    return out
 
 
 def main():
@@ -99,6 +131,7 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    classify = not args.no_classify
 
     geo = getattr(synthetic, args.size)
     Hc, Wc, n, nwin = geo["Hc"], geo["Wc"], args.n, args.windows
@@ -138,19 +171,36 @@ def main():
     out.nseg = nseg.data_ptr()
     out.iters = iters.data_ptr()
 
+    def segment_step():
+        ctx.batch_run_raw(inp, params, out)      # synchronous on the library's own stream
+
     clf = None
     kept_total = [0, 0]
-    if args.classify:
+    if classify:
+        # Random-init weights of the architecture (no checkpoint travels to the GPU box).  Random weights put every
+        # crop in one class, so the head bias is calibrated on the stream's own segments: with both pre-activations
+        # held positive (ReLU inactive) the score difference is affine in the bias, and the median segment is put on
+        # the decision boundary -- about half of the segments are then kept, and both branches of the keep rule and
+        # the per-frame reduction see real work.
         from swiftwatcher_amd.segment_classification import SegmentClassifier, SqueezeNet10
         torch.manual_seed(20190816)
-        clf = SegmentClassifier.from_state_dict(SqueezeNet10(2).state_dict(), device=dev, batch_size=2048)
+        sd = SqueezeNet10(2).state_dict()
+        big = 50.0
+        sd["classifier.1.bias"] = torch.tensor([big, big])
+        segment_step()
+        probe = SegmentClassifier.from_state_dict(sd, device=dev, batch_size=args.cls_batch, cropped=not args.full_network)
+        s0, _ = probe.scores_from_device(ctx, inp, (Hc, Wc), segs, nseg, seg_cap)
+        d = (s0[:, 1] - s0[:, 0]).double()
+        sd["classifier.1.bias"] = torch.tensor([big, big - float(d.median())])
+        del probe
+        clf = SegmentClassifier.from_state_dict(sd, device=dev, batch_size=args.cls_batch, cropped=not args.full_network)
 
     def step():
-        ctx.batch_run_raw(inp, params, out)      # synchronous on the library's own stream
+        segment_step()
         if clf is not None:
             scores, fidx = clf.scores_from_device(ctx, inp, (Hc, Wc), segs, nseg, seg_cap)
             keep = torch.max(scores, 1)[1] == 1                      # segment_classification.py:36-39
-            per_frame = torch.bincount(fidx[keep].to(torch.int64), minlength=F)
+            per_frame = torch.bincount(fidx[keep].to(torch.int64), minlength=F)      # kept segments of every frame
             kept_total[0] = int(per_frame.sum().item())
             kept_total[1] = int(scores.shape[0])
 
@@ -159,49 +209,81 @@ def main():
         swd.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn):
+        """EXACTLY args.steps steps between two fences; library kernel families timed by HIP events on its stream."""
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        if clf is not None:
+            clf.net_time()
+            clf.timing = fn is step
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        prof = ctx.prof()
+        bpe = ctx.pass_bytes_per_element
+        ctx.prof_enable(False)
+        net = clf.net_time() if clf is not None else (0.0, 0, 0)
+        if clf is not None:
+            clf.timing = False
+        return swd.max_over_ranks(dt), prof, bpe, net
+
     for _ in range(args.warmup):
         step()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ctx.prof()
-    ctx.prof_enable(False)
+    redo0 = ctx.redo_batches
+    dt_max, prof, bpe, net = timed(step)
+    # second loop: the image_filtering part alone (same data, same step count)
+    seg_only = timed(segment_step) if clf is not None else None
+    redo = ctx.redo_batches - redo0
 
     # ---- per-rank counts gathered over RCCL (the only collective of the path) ----
     it_host = iters.cpu().numpy()
     nseg_host = nseg.cpu().numpy()
-    # every rank is one "video" here: (segments found, IALM iterations, frames processed)
-    table = swd.gather_counts({rank: (int(nseg_host.sum()), int(it_host.sum()), F * args.steps)}, world)
+    # every rank is one "video" here: (segments kept or found, IALM iterations, frames processed)
+    table = swd.gather_counts({rank: (kept_total[0] if clf else int(nseg_host.sum()), int(it_host.sum()), F * args.steps)}, world)
     total_frames = int(table[:, 2].sum())
-    dt_max = swd.max_over_ranks(dt)
 
     if rank == 0:
-        pass_ms, pass_launches = prof["ialm_pass"]
-        # exact algorithmic bytes streamed by the full passes of ONE step (same every step: same data)
         elems = n * P
         variant = args.variant if args.variant else 3
-        BYTES_STEADY, BYTES_FIRST, BYTES_ONCE = PASS_BYTES[variant]
-        step_bytes = int(sum(BYTES_ONCE + BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems
-        total_bytes = step_bytes * args.steps
-        if variant == 3:
-            # exact: the library books what each window-iteration had to move (the passes far from convergence skip
-            # the sparse-image stores and most of the f16 copy of Y/mu)
-            total_bytes = int(ctx.pass_bytes_per_element * elems)
-        achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_ialm_pass.json")
-        if os.path.exists(pmc_file):
-            try:       # PMC passes are separate rocprofv3 runs (tools/pmc_pass.sh); valid for the same n and ROI
-                pmc = json.load(open(pmc_file))
-                if pmc.get("n") == n and pmc.get("P") == P and pmc.get("variant", 2) == variant:
-                    traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
-            except Exception:
-                traffic = None
+
+        def pass_roofline(prof, bpe):
+            pass_ms, pass_launches = prof["ialm_pass"]
+            BYTES_STEADY, BYTES_FIRST, BYTES_ONCE = PASS_BYTES[variant]
+            total_bytes = int(sum(BYTES_ONCE + BYTES_FIRST + BYTES_STEADY * (int(k) - 1) for k in it_host if k > 0)) * elems * args.steps
+            if variant == 3:
+                # exact: the library books what each window-iteration had to move (the passes far from convergence skip
+                # the sparse-image stores and most of the f16 copy of Y/mu)
+                total_bytes = int(bpe * elems)
+            achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+            traffic = None
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_ialm_pass.json")
+            if os.path.exists(pmc_file):
+                try:       # PMC passes are separate rocprofv3 runs (tools/pmc_pass.sh); valid for the same n and ROI
+                    pmc = json.load(open(pmc_file))
+                    if pmc.get("n") == n and pmc.get("P") == P and pmc.get("variant", 2) == variant:
+                        traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
+                except Exception:
+                    traffic = None
+            return {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
+                    "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
+                    "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
+                    "pass_variant": variant,
+                    # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
+                    # replaces): informational, NOT what "achieved" uses
+                    "survey_pricing": {"bytes_per_element_iteration": 33,
+                                       "achieved": round(33.0 * elems * float(it_host.sum()) * args.steps / (pass_ms * 1e-3) / 1e9, 1)
+                                       if pass_ms > 0 else 0.0}}
+
+        def kernel_ms(prof):
+            return {k: round(v[0] / args.steps, 3) for k, v in prof.items() if isinstance(v, tuple)}
+
+        workload = ("synthetic 1080p ROI stream %dx%d, frame-batch=%d, %d windows/step/GPU: image_filtering HIP kernels "
+                    "(gray, RPCA/IALM, bilateral, threshold, opening, CCL, region props)" % (Wc, Hc, n, nwin))
         res = {
             "metric": "frames/sec (segment+classify) on 1080p ROI batches" if clf else "frames/sec (segment) on 1080p ROI batches",
             "value": round(total_frames / dt_max, 2),
@@ -209,30 +291,37 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic 1080p ROI stream %dx%d, frame-batch=%d, %d windows/step/GPU, "
-                                   "image_filtering HIP kernels (gray, RPCA/IALM, bilateral, threshold, opening, CCL, "
-                                   "region props)" % (Wc, Hc, n, nwin),
+            "dtype": "f64 (image_filtering), f32 (CNN)" if clf else "f64", "data": "synthetic",
+            "config": {"workload": workload + (" + segment_classification CNN on every segment" if clf else ""),
                        "roi": [Wc, Hc], "frame_batch": n, "windows_per_step": nwin,
                        "ialm_iters_mean": round(float(it_host.mean()), 2),
                        "segments_per_frame": round(float(nseg_host.mean()), 2),
-                       "classify": ("every segment through SqueezeNet-1.0 (fp32, receptive-field cropped, random-init "
-                                    "weights): %d segments/step, %d kept" % (kept_total[1], kept_total[0])) if clf else
-                                   "not in this config (BASELINE configs[1] is image_filtering only; --classify adds it)",
+                       "classify": ("every segment through SqueezeNet-1.0 (fp32, eval mode, %s, random-init weights with the "
+                                    "head bias calibrated on the stream): %d segments/step, %d kept"
+                                    % ("full 224x224 network" if args.full_network else "receptive-field cropped",
+                                       kept_total[1], kept_total[0])) if clf else "off (--no-classify)",
                        "parallelism": "windows sharded per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
-                         "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
-                         "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
-                         "pass_variant": variant,
-                         # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
-                         # replaces): informational, NOT what "achieved" uses
-                         "survey_pricing": {"bytes_per_element_iteration": 33,
-                                            "achieved": round(33.0 * elems * float(it_host.sum()) * args.steps / (pass_ms * 1e-3) / 1e9, 1)
-                                            if pass_ms > 0 else 0.0}},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if isinstance(v, tuple)},
+            "redo_batches": int(redo),
+            "roofline": pass_roofline(prof, bpe),
+            "kernel_ms_per_step": kernel_ms(prof),
         }
+        if clf is not None:
+            net_ms, rows, calls = net
+            executed, useful = clf.cropped.macs_per_segment() if clf.cropped is not None else (732_600_000, 732_600_000)
+            flop = 2.0 * executed * rows
+            res["roofline_cnn"] = {
+                "bound": "mfma", "kernel": "SqueezeNet-1.0 forward (MIOpen convolutions + HIP glue), torch.cuda events on torch's stream",
+                "achieved": round(flop / (net_ms * 1e-3) / 1e12, 2) if net_ms > 0 else 0.0, "peak": F32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(flop / (net_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4) if net_ms > 0 else 0.0,
+                "dtype": "f32", "macs_per_segment_executed": executed, "macs_per_segment_useful": useful,
+                "macs_per_segment_full_network": 732_600_000, "rows_per_step": int(rows / args.steps),
+                "segments_per_step": kept_total[1], "forwards_per_step": int(calls / args.steps),
+                "net_ms_per_step": round(net_ms / args.steps, 3),
+                "segments_per_s_in_network": round(rows / (net_ms * 1e-3), 1) if net_ms > 0 else 0.0}
+            so_dt, so_prof, so_bpe, _ = seg_only
+            res["segment_only"] = {"metric": "frames/sec (segment) on 1080p ROI batches", "value": round(total_frames / so_dt, 2),
+                                   "ms_per_step": round(so_dt / args.steps * 1e3, 3), "roofline": pass_roofline(so_prof, so_bpe),
+                                   "kernel_ms_per_step": kernel_ms(so_prof)}
         if args.host_input:
             host = frames.cpu().numpy()
             hin = _lib.Input(frames=host.ctypes.data, mem=_lib.MEM_HOST, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
@@ -240,9 +329,9 @@ def main():
             ctx.batch_run_raw(hin, params, out)
             t1 = time.perf_counter()
             ctx.batch_run_raw(hin, params, out)
-            res["pcie_inclusive_frames_per_s"] = round(F / (time.perf_counter() - t1), 2)
+            res["pcie_inclusive_segment_frames_per_s"] = round(F / (time.perf_counter() - t1), 2)
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows)
+            res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:

@@ -252,6 +252,8 @@ int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
 /* M-state pass only: 1 (default) = statistics and the first iteration's Gram matrix come from one read of X on the
  * integer matrix cores wherever the first shrinkage provably removes nothing; 0 = always the f64 start pass. */
 int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on);
+/* Windows of the last swk_batch_run / swk_ialm whose start came from the integer kernel (the others ran the f64 start pass). */
+int32_t swk_last_integer_start_windows(swk_ctx *ctx, int32_t *windows);
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
 /* M-state pass: algorithmic bytes per matrix element moved by all its launches since swk_prof_reset, summed over
  * windows (each window-iteration counts X 1 + M 8 (+8 read) + U 2 or 1/8 each way + 1 when the sparse image is

@@ -82,6 +82,7 @@ _SIGS = {
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_sparse_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_set_integer_start": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_last_integer_start_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -137,11 +138,33 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
+class _SerialisedLib:
+    """The library's entry points with a lock held for the duration of every call.  A swk_ctx is not thread-safe
+    (include/swk.h), ctypes drops the GIL while a call runs, and the counting loop's producer thread (pipeline.py,
+    windows_per_call > 1) segments the next windows while the consumer thread cuts classifier inputs on the same
+    context: every call on one Context is therefore serialised here."""
+
+    def __init__(self, lib, lock):
+        self._lib, self._lock = lib, lock
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        lock = self._lock
+
+        def call(*args):
+            with lock:
+                return fn(*args)
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
 class Context:
-    """One per process per GPU (swk_ctx).  Not thread-safe."""
+    """One per process per GPU (swk_ctx).  The C object is not thread-safe; this wrapper serialises calls on it."""
 
     def __init__(self, device=0, max_windows=0, max_n=0, max_Hc=0, max_Wc=0):
-        self._lib = load()
+        self._lock = threading.RLock()
+        self._lib = _SerialisedLib(load(), self._lock)
         self._h = ctypes.c_void_p()
         rc = self._lib.swk_ctx_create(device, max_windows, max_n, max_Hc, max_Wc, ctypes.byref(self._h))
         if rc != 0:
@@ -204,6 +227,12 @@ class Context:
     def pass_bytes_per_element(self):
         v = ctypes.c_double(0)
         self._check(self._lib.swk_prof_pass_bytes_per_element(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def last_integer_start_windows(self):
+        v = ctypes.c_int32(0)
+        self._check(self._lib.swk_last_integer_start_windows(self._h, ctypes.byref(v)))
         return v.value
 
     @property
@@ -402,11 +431,13 @@ def lsap(cost):
 
 
 _default_ctx = {}
+_ctx_lock = threading.Lock()
 
 
 def default_context(device=0):
     """Process-wide context used by the image_filtering.* drop-in functions."""
-    ctx = _default_ctx.get(device)
-    if ctx is None:
-        ctx = _default_ctx[device] = Context(device)
+    with _ctx_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None:
+            ctx = _default_ctx[device] = Context(device)
     return ctx

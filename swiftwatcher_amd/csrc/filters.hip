@@ -454,9 +454,10 @@ void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W,
     const int ntx = (W + kTW - 1) / kTW, nty = (H + kTH - 1) / kTH;
     const size_t plane = (size_t)F * H * W;
     // the kernel stores nonzero results only: outputs start cleared
-    (void)hipMemsetAsync(open_out, 0, plane, s);
-    if (bil_out) (void)hipMemsetAsync(bil_out, 0, plane, s);
-    if (thr_out) (void)hipMemsetAsync(thr_out, 0, plane, s);
+    hipError_t me = hipMemsetAsync(open_out, 0, plane, s);
+    if (me == hipSuccess && bil_out) me = hipMemsetAsync(bil_out, 0, plane, s);
+    if (me == hipSuccess && thr_out) me = hipMemsetAsync(thr_out, 0, plane, s);
+    if (me != hipSuccess) { g_launch_error = (int)me; return; }
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
         const int64_t o = (int64_t)f0 * H * W;

@@ -284,12 +284,10 @@ static void launch_v1(hipStream_t s, const IalmBuffers &b)
 {
     const int n8 = (b.n + 7) & ~7;
     const size_t lds = (size_t)2 * n8 * kLdsRow * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v1<MODE, WE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxN * kLdsRow * 8);
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_v1<MODE, WE>, 2 * kMaxN * kLdsRow * 8, attr_mask)) return;
     hipLaunchKernelGGL((k_ialm_pass_v1<MODE, WE>), dim3(b.nblk, b.nwin), dim3(64), lds, s, b);
+    note_launch();
 }
 
 void launch_ialm_pass_v2(hipStream_t s, const IalmBuffers &b, int mode);   // ialm_mfma.hip

@@ -505,13 +505,10 @@ __global__ __launch_bounds__(256) void k_select_sparse(IalmBuffers b)
 template <int NB, int MODE, bool FULL>
 static void launch3_full(hipStream_t s, const IalmBuffers &b, int sel)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v3<NB, MODE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)V2Cfg<NB>::lds_bytes);
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_v3<NB, MODE, FULL>, V2Cfg<NB>::lds_bytes, attr_mask)) return;
     hipLaunchKernelGGL((k_ialm_pass_v3<NB, MODE, FULL>), dim3(b.nblk, b.nwin), dim3(256), V2Cfg<NB>::lds_bytes, s, b, sel);
+    note_launch();
 }
 
 template <int NB>
@@ -553,13 +550,10 @@ bool ialm_v2_supported(int n) { return n >= 1 && n <= kMaxN; }
 template <int NB, int MODE, bool WE, bool FULL>
 static void launch_full(hipStream_t s, const IalmBuffers &b)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ialm_pass_v2<NB, MODE, WE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)V2Cfg<NB>::lds_bytes);
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_v2<NB, MODE, WE, FULL>, V2Cfg<NB>::lds_bytes, attr_mask)) return;
     hipLaunchKernelGGL((k_ialm_pass_v2<NB, MODE, WE, FULL>), dim3(b.nblk, b.nwin), dim3(256), V2Cfg<NB>::lds_bytes, s, b);
+    note_launch();
 }
 
 template <int NB, int MODE, bool WE>

@@ -38,6 +38,10 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
     const int tid = threadIdx.x, nblk = b.nblk;
     IalmWin &st = b.win[w];
     if (st.done) return false;
+    // every thread takes its copy of the window state BEFORE the reduction's barriers: thread 0 rewrites ru / wu
+    // further down, and all waves must take the same branches around the barriers that follow
+    const bool full = st.ru != 0;
+    const double dnorm = st.dnorm;
     if (k >= 1) {
         double acc = 0.0;
         for (int i = tid; i < nblk; i += kSmallThreads) acc += b.zzpart[(int64_t)w * nblk + i];
@@ -49,8 +53,7 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         }
         // a pass that read all of U_{k-1} delivers ||Z_k||^2; one that read only frames 0..3 of it (IalmWin::ru == 0)
         // delivers the sum over those frames: a LOWER bound
-        const bool full = st.ru != 0;
-        const double ratio = sqrt(red[0]) / st.dnorm;            // :297
+        const double ratio = sqrt(red[0]) / dnorm;               // :297
         if (tid == 0) {
             // bookkeeping for the roofline: what pass k had to move per element (M-state pass; 1/16-byte units):
             // X 1 + M 8 written (+ 8 read after the first pass) + U 2 or 2/16 each way + the sparse image if stored
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(IalmBuffers b)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * n) return;
     double *gp = b.gpart + (int64_t)w * b.nblk * n * n;
+    if (((idx / n) >> 4) > ((idx % n) >> 4)) return;       // the passes only write frame-block pairs ib <= jb
     double acc = 0.0;
     for (int bk = 0; bk < b.nblk; ++bk) acc += gp[(int64_t)bk * n * n + idx];
     gp[idx] = acc;
@@ -403,12 +407,10 @@ void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
 template <int NB>
 static void launch_small_nb(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ialm_small<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NsCfg<NB>::lds_bytes);
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_small<NB>, NsCfg<NB>::lds_bytes, attr_mask)) return;
     hipLaunchKernelGGL((k_ialm_small<NB>), dim3(b.nwin), dim3(kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda, tol, maxiter, method);
+    note_launch();
 }
 
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)

@@ -10,6 +10,8 @@
 
 using namespace swk;
 
+namespace swk { int g_launch_error = 0; }
+
 namespace {
 
 std::string g_create_error;
@@ -46,6 +48,7 @@ struct swk_ctx {
     int ialm_variant = 0;
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
+    int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 256.0;      // M-state pass: ||Z|| every other iteration while above 256 x tol (<= 0: every iteration)
@@ -183,6 +186,11 @@ int sync(swk_ctx *ctx)
     for (int g = 0; g < ctx->ngroups_ready; ++g) HIPCHK(ctx, hipStreamSynchronize(ctx->gstream[g]));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
+    if (g_launch_error) {          // a launcher could not set a kernel attribute or start a kernel
+        const hipError_t e = (hipError_t)g_launch_error;
+        g_launch_error = 0;
+        HIPCHK(ctx, e);
+    }
     drain_prof(ctx);
     return SWK_OK;
 }
@@ -411,7 +419,11 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     std::vector<IalmWin> hw(nwin);
     HIPCHK(ctx, hipMemcpy(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost));
     std::vector<int32_t> it(nwin);
-    for (int w = 0; w < nwin; ++w) { it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; ctx->pass_b16 += hw[w].pass_b16; }
+    ctx->last_int_start = 0;
+    for (int w = 0; w < nwin; ++w) {
+        it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; ctx->pass_b16 += hw[w].pass_b16;
+        ctx->last_int_start += hw[w].int_gram ? 1 : 0;
+    }
     if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
     if (d_iters) HIPCHK(ctx, hipMemcpy(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice));
     return SWK_OK;
@@ -567,6 +579,12 @@ int32_t swk_prof_pass_bytes_per_element(swk_ctx *ctx, double *bytes)
 {
     if (!ctx || !bytes) return SWK_ERR_ARG;
     *bytes = (double)ctx->pass_b16 / 16.0;
+    return SWK_OK;
+}
+int32_t swk_last_integer_start_windows(swk_ctx *ctx, int32_t *windows)
+{
+    if (!ctx || !windows) return SWK_ERR_ARG;
+    *windows = ctx->last_int_start;
     return SWK_OK;
 }
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)

@@ -8,6 +8,23 @@ namespace swk {
 
 constexpr int kMaxN = 64;          // frames per window supported by the IALM kernels
 
+// Kernels that take more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute
+// belongs to the (kernel, device) pair: `mask` (one static per kernel instantiation) keeps a bit per device it has been
+// set on, so a second context on another device of the same process gets it too.  A failure is parked in
+// g_launch_error and surfaces at the context's next sync().
+extern int g_launch_error;
+inline bool ensure_dyn_lds(const void *fn, size_t bytes, unsigned long long &mask)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev < 64 && ((mask >> dev) & 1ull)) return true;
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { g_launch_error = (int)e; return false; }
+    if (dev < 64) mask |= 1ull << dev;
+    return true;
+}
+inline void note_launch() { hipError_t e = hipGetLastError(); if (e != hipSuccess) g_launch_error = (int)e; }
+
 // Per-window scalar state of the IALM loop (device resident).
 struct IalmScal { double mu, inv_mu, thr; };
 struct IalmWin {

@@ -11,14 +11,19 @@ import torch.distributed as dist
 COUNT_FIELDS = 3            # per video: predicted swifts, rejected events, frames processed
 
 
-def init(backend=None):
+def init(backend=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
-    Returns (rank, world, local_rank).  With WORLD_SIZE unset or 1 nothing is initialised."""
+    Returns (rank, world, local_rank).  With WORLD_SIZE unset or 1 nothing is initialised unless force=True
+    (a one-rank group: the collectives below then really run on the backend, which is how the single-GPU test
+    exercises the RCCL path)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -53,7 +58,7 @@ def gather_counts(local_counts, n_items):
         vals = local_counts[idx]
         mine[slot, 0] = idx
         mine[slot, 1:] = torch.tensor([int(v) for v in vals], dtype=torch.int64)
-    if world > 1:
+    if dist.is_initialized():
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
     else:
@@ -74,7 +79,7 @@ def gather_counts(local_counts, n_items):
 
 def max_over_ranks(value):
     """The benchmark's clock: the slowest rank's elapsed time."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -82,7 +87,7 @@ def max_over_ranks(value):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 

@@ -151,8 +151,13 @@ def get_segment_properties(frame):
 
 def extract_segment_images(segments, frame, min_seg_size, crop_region):
     """image_filtering.py:338-369: expand each bbox to at least min_seg_size (floor/ceil split),
-    translate by the crop origin and slice the FULL frame (views, no clamping -- same silent
-    mis-slicing as the reference when the box leaves the frame)."""
+    translate by the crop origin and slice the FULL frame (views).
+
+    One deliberate deviation: a box whose top or left edge leaves the frame is intersected with the frame.
+    The reference's unchecked slice wraps a negative start around (numpy semantics), which yields an empty or
+    unrelated crop that its classifier then fails on; boxes leaving the bottom / right edge are clipped by numpy
+    in the reference too.  swk_segment_inputs (the device-resident path) uses the same rule, so both
+    classification paths see the same crop for every segment."""
     images = []
     oy, ox = crop_region[0][1], crop_region[0][0]
     for segment in segments:
@@ -166,5 +171,5 @@ def extract_segment_images(segments, frame, min_seg_size, crop_region):
             d = min_seg_size[1] - w
             c0 -= math.floor(d / 2)
             c1 += math.ceil(d / 2)
-        images.append(frame[r0 + oy:r1 + oy, c0 + ox:c1 + ox])
+        images.append(frame[max(r0 + oy, 0):max(r1 + oy, 0), max(c0 + ox, 0):max(c1 + ox, 0)])
     return images

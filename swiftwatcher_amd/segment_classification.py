@@ -165,6 +165,30 @@ class CroppedSqueezeNet10:
         if self.memory_format == torch.channels_last:
             model.to(memory_format=torch.channels_last)
 
+    def macs_per_segment(self):
+        """Multiply-accumulates the convolutions of one forward execute per segment: (executed, useful).  "executed"
+        counts every output the kernels produce (the 1x1 expands run over the whole squeeze tile, ring included);
+        "useful" only the outputs the next layer reads.  The full 224 x 224 network does 0.7326 G."""
+        m = self.model
+        c1 = m.features[0]
+        side = (self.IN_HI - self.IN_LO + 1 - 7) // 2 + 1
+        executed = useful = side * side * c1.out_channels * c1.in_channels * 49
+        last_n = None
+        for kind, layer, tile, off, n, pad, crop in self.plan:
+            if kind != "fire":
+                continue
+            t = tile.shape[2] + pad[0] + pad[1]
+            sq, e1, e3 = layer.squeeze, layer.expand1x1, layer.expand3x3
+            executed += n * n * sq.out_channels * sq.in_channels
+            executed += t * t * e1.out_channels * e1.in_channels + (t - 2) ** 2 * e3.out_channels * e3.in_channels * 9
+            useful += n * n * sq.out_channels * sq.in_channels
+            useful += crop[1] ** 2 * (e1.out_channels * e1.in_channels + e3.out_channels * e3.in_channels * 9)
+            last_n = crop[1]
+        head = m.classifier[1]
+        executed += last_n * last_n * head.out_channels * head.in_channels
+        useful += last_n * last_n * head.out_channels * head.in_channels
+        return int(executed), int(useful)
+
     def _buffers(self, batch):
         """Persistent per-layer tiles for up to `batch` segments.  Their rings hold the background values and are
         written once; a forward pass only overwrites the live centres."""
@@ -356,6 +380,10 @@ class SegmentClassifier:
         # Pad(100) puts zeros around the 24x24 patch BEFORE ToTensor/Normalize: the border is (0-mean)/std
         self._border = ((0.0 - mean) / std).expand(1, 3, 224, 224).contiguous()
         self.cropped = CroppedSqueezeNet10(self.model, ((0.0 - mean) / std).view(3)) if cropped else None
+        # measurement hook (bench.py): with timing on, every network forward is bracketed by events on torch's
+        # current stream; net_time() sums them
+        self.timing = False
+        self._events = []
 
     def preprocess(self, segment_images, window=False):
         """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device, or with
@@ -392,7 +420,24 @@ class SegmentClassifier:
 
     def _run(self, x, k):
         """Scores of the first k rows of x (x has _bucket(k) rows)."""
+        if self.timing and self.device.type == "cuda":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = (self.cropped(x) if self.cropped is not None else self.model(x))[:k]
+            b.record()
+            self._events.append((a, b, int(x.shape[0])))
+            return out
         return (self.cropped(x) if self.cropped is not None else self.model(x))[:k]
+
+    def net_time(self, reset=True):
+        """(milliseconds, rows pushed through the network, forwards) of the timed forwards since the last reset."""
+        if self._events:
+            torch.cuda.synchronize(self.device)
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._events)
+        rows, calls = sum(r for _, _, r in self._events), len(self._events)
+        if reset:
+            self._events = []
+        return ms, rows, calls
 
     def scores(self, segment_images):
         out = []

@@ -239,3 +239,58 @@ def test_device_resident_segment_inputs_match_host_path(tmp_path):
         ctx.segment_inputs(inp_bad, (FH, FW), segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN, IMAGENET_STD,
                            x.data_ptr(), 4)
     ctx.close()
+
+
+# ------------------------------------------------------------------ the reference's own weights (model.pt)
+def _model_pt_fixture(golden_dir):
+    """tests/golden/classifier_model_pt.npz (oracle/make_classifier_goldens.py): model.pt's 52 tensors as arrays,
+    96 seeded crops and their eval-mode scores from the oracle."""
+    g = np.load(os.path.join(golden_dir, "classifier_model_pt.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
+    crops = [g["crop%d" % i] for i in range(int(g["count"]))]
+    return sd, crops, g["scores"], g["keep"]
+
+
+def test_model_pt_weights_load_strict_and_oracle_reproduces_fixture(golden_dir):
+    """The real weight file's key set / shapes match the restated topology (strict load, no reference checkout
+    needed), and the oracle reproduces the committed scores on this machine."""
+    from swiftwatcher_amd.segment_classification import SqueezeNet10, SegmentClassifier
+    from oracle import classifier_ref as ref
+    sd, crops, scores, keep = _model_pt_fixture(golden_dir)
+    assert len(sd) == 52 and sum(v.numel() for v in sd.values()) == 736450
+    SqueezeNet10(2).load_state_dict(sd, strict=True)
+    if os.path.exists(REF_MODEL):      # build container: the arrays ARE the checkpoint's tensors
+        disk = torch.load(REF_MODEL, map_location="cpu", weights_only=True)
+        assert set(disk) == set(sd) and all(torch.equal(disk[k].float(), sd[k]) for k in sd)
+    got, got_keep = ref.classify(sd, crops[:32])
+    np.testing.assert_allclose(got, scores[:32], atol=2e-4, rtol=1e-4)
+    assert list(got_keep) == list(keep[:32])
+    # the product's host logic on the torch CPU kernels, full and receptive-field cropped
+    for cropped in (False, True):
+        clf = SegmentClassifier.from_state_dict(sd, device="cpu", cropped=cropped, batch_size=16)
+        s = clf.scores(crops[:32]).numpy()
+        np.testing.assert_allclose(s, scores[:32], atol=2e-4, rtol=1e-4)
+        assert list(np.argmax(s, 1) == 1) == list(keep[:32])
+    assert 0 < keep.sum() < len(keep)
+
+
+@pytest.mark.gpu
+def test_gpu_model_pt_scores_and_decisions(golden_dir):
+    """SURVEY 8(c) fixture (9) on the MI355X: the full 224 x 224 network and the receptive-field cropped one, loaded
+    with the reference's own weights, within 2e-4 of the oracle's eval-mode scores on all 96 crops; decisions equal
+    (the smallest margin in the fixture is 0.27); both keep and drop occur."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    sd, crops, scores, keep = _model_pt_fixture(golden_dir)
+    margin = np.abs(scores[:, 1] - scores[:, 0])
+    assert margin.min() > 0.1
+    for cropped in (False, True):
+        clf = SegmentClassifier.from_state_dict(sd, cropped=cropped, batch_size=64)
+        assert clf.device.type == "cuda"
+        s = clf.scores(crops).cpu().numpy()
+        np.testing.assert_allclose(s, scores, atol=2e-4, rtol=1e-4)
+        assert list(np.argmax(s, 1) == 1) == list(keep)
+    segs = _segments(np.random.default_rng(3), len(crops))
+    for sgm, c in zip(segs, crops):
+        sgm.segment_image = c
+    kept = clf(segs)
+    assert len(kept) == int(keep.sum()) and [s.label for s in kept] == list(range(1, len(kept) + 1))

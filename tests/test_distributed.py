@@ -60,3 +60,43 @@ def test_single_process_without_group():
     table = d.run_sharded(3, lambda i: (i, 0, 1))
     assert table.tolist() == [[0, 0, 1], [1, 0, 1], [2, 0, 1]]
     assert d.max_over_ranks(3.5) == 3.5
+
+
+_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+import torch
+from swiftwatcher_amd import distributed as d
+r, w, local = d.init({backend!r}, force=True)
+assert (r, w) == (0, 1) and torch.distributed.is_initialized() and torch.distributed.get_backend() == {backend!r}
+table = d.run_sharded(3, lambda i: (10 + i, i, 21))           # all_gather on the backend, one rank
+assert table.tolist() == [[10, 0, 21], [11, 1, 21], [12, 2, 21]], table
+assert d.max_over_ranks(2.5) == 2.5                             # all_reduce(MAX)
+d.barrier()
+torch.distributed.destroy_process_group()
+print("one-rank group ok on", {backend!r})
+"""
+
+
+def _one_rank_group(backend):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _ONE_RANK.format(root=root, port=_free_port(), backend=backend)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "one-rank group ok" in p.stdout
+
+
+def test_one_rank_group_runs_the_collectives_gloo():
+    _one_rank_group("gloo")
+
+
+@pytest.mark.gpu
+def test_one_rank_group_runs_the_collectives_rccl():
+    """The per-video count gather, the bench clock's all_reduce(MAX) and the barrier on backend "nccl" (= RCCL on ROCm)
+    with a one-rank group on the GPU: the collective code path of distributed.py executes on hardware (a child
+    process, so the test session itself never joins a process group)."""
+    _one_rank_group("nccl")

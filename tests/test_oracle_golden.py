@@ -54,7 +54,37 @@ def test_regionprops(golden_dir):
         np.testing.assert_array_equal(np.array([s["centroid"] for s in got]), g["centroid%d" % i])
 
 
-IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64", "ialm_107x214x21"]
+# ialm_47x94x21 = BASELINE config 1's ROI (480p clip, chimney 76 px wide) at the CLI's queue size: 92.8 k elements, where
+# 0.008 ||X||_F < 1.8 max(X) and the first shrinkage already clips the brightest sky pixels (23 iterations).
+IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64", "ialm_107x214x21", "ialm_47x94x21"]
+# the BASELINE workload sizes: inputs regenerated from the seed (oracle/scenes.py), outputs of the reference stored as
+# iteration count, sha256 of the sparse image and A / E on sampled pixel rows (oracle/make_goldens_r2.py)
+SEEDED_CASES = ["ialm_212x424x21_seeded", "ialm_212x424x64_seeded", "ialm_425x850x21_seeded"]
+
+
+def seeded_frames(g):
+    """Regenerate a seeded fixture's input window and prove it is the one the reference saw."""
+    from oracle.scenes import scene, sha256
+    n, H, W = (int(v) for v in g["shape"])
+    frames = scene(np.random.default_rng(int(g["seed"])), n, H, W, blobs=int(g["blobs"]))
+    assert sha256(frames) == str(g["frames_sha256"]), "scene generator no longer reproduces the fixture's input"
+    return frames
+
+
+@pytest.mark.parametrize("name", SEEDED_CASES)
+def test_ialm_numpy_restatement_at_baseline_sizes(golden_dir, name):
+    from oracle.scenes import sha256
+    g = _load(golden_dir, name + ".npz")
+    frames = seeded_frames(g)
+    n, H, W = frames.shape
+    A, E, k = orc.ialm(np.transpose(frames.reshape(n, H * W)), return_iters=True)
+    assert k == int(g["iters"])
+    rows = g["rows"]
+    np.testing.assert_allclose(A[rows], g["A_rows"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(E[rows], g["E_rows"], atol=1e-6, rtol=0)
+    sparse = orc.rpca_epilogue(E).T.reshape(n, H, W)
+    np.testing.assert_array_equal(sparse.reshape(n, -1).astype(np.int64).sum(axis=1), g["sparse_frame_sums"])
+    assert sha256(sparse) == str(g["sparse_sha256"])
 
 
 @pytest.mark.parametrize("name", IALM_CASES)
@@ -74,10 +104,17 @@ def test_ialm_numpy_restatement(golden_dir, name):
 
 
 def test_ialm_null_padded_window_is_defined(golden_dir):
-    """Padded windows: the reference's own output is LAPACK-arbitrary (see ialm_defined).
-    The fixture documents that: the oracle's defined behaviour must zero the null frames,
-    equal the plain algorithm run on the real frames alone, and stay close to (but is not
-    required to equal) what the reference happened to produce in the build container."""
+    """Padded windows (the last window of every video, io_video.py:40-44).  The reference's own output there is
+    LAPACK-arbitrary: a zero column gives the SVD a zero singular value, the always-full `svp` (:285) turns its
+    arbitrary left vector u into A[:, j] = -(1/mu) u with entries of hundreds of grey levels, and that leaks into
+    the real frames from iteration 2 on (see ialm_defined).  This project's DEFINED behaviour excludes the null
+    columns.  The fixture is what the reference produced under numpy 1.26 in the build container; this test states
+    exactly how far the three parties are apart instead of allowing a margin:
+
+      reference on numpy 1.26 vs the same statements on numpy 2.2:  3.1 % of the real-frame pixels differ, by <= 2
+      defined vs reference (1.26):                                   5.8 % differ, by <= 9 grey levels
+      pixels above the to-zero threshold of 15 (what segmentation sees): 542 in the reference, 539 defined, 539 common
+    """
     g = _load(golden_dir, "ialm_64x96x21_null5.npz")
     frames = g["frames"]
     n, H, W = frames.shape
@@ -90,9 +127,27 @@ def test_ialm_null_padded_window_is_defined(golden_dir):
     np.testing.assert_array_equal(A[:, nz:], A2)
     sparse = np.stack(orc.rpca(list(frames)))
     assert not sparse[:nz].any()
-    ref = g["sparse"][nz:]
-    assert np.mean(sparse[nz:] != ref) < 0.10
-    assert np.abs(sparse[nz:].astype(int) - ref.astype(int)).max() <= 16
+    ref = g["sparse"][nz:].astype(int)
+    d = np.abs(sparse[nz:].astype(int) - ref)
+    assert (d > 0).mean() < 0.06 and d.max() <= 9                     # measured: 0.0575, 9
+    fg_ref, fg_def = ref > 15, sparse[nz:] > 15
+    assert int(fg_ref.sum()) == 542 and int((fg_ref & fg_def).sum()) == int(fg_def.sum()) >= 539
+    # the reference is not reproducible against ITSELF on these windows: the faithful restatement under this
+    # interpreter's LAPACK differs from the fixture too (wherever that stops being true the fixture can be pinned)
+    _, E22 = orc.ialm(X)
+    s22 = orc.rpca_epilogue(E22).T.reshape(n, H, W)[nz:].astype(int)
+    d22 = np.abs(s22 - ref)
+    assert d22.max() <= 3 and (d22 > 0).mean() < 0.05
+    # downstream of the filters: same segment count on all but at most one real frame, same boxes on most
+    same_count = same_boxes = 0
+    for i in range(n - nz):
+        segs = []
+        for img in (g["sparse"][nz + i], sparse[nz + i]):
+            opened = orc.grey_open_u8(orc.thresh_tozero_u8(orc.bilateral_u8(img)))
+            segs.append(orc.regionprops_u8(orc.labels_to_u8(orc.ccl_u8(opened)[1])))
+        same_count += len(segs[0]) == len(segs[1])
+        same_boxes += [s["bbox"] for s in segs[0]] == [s["bbox"] for s in segs[1]]
+    assert same_count >= n - nz - 1 and same_boxes >= n - nz - 2       # measured: 15 and 14 of 16
 
 
 def test_ccl_matches_scipy_raster_order():
