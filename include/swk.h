@@ -220,6 +220,25 @@ int32_t swk_track_costs(const double *prev_c, const double *prev_hist0, const ui
  * with its tie rule; col4row[i] = column assigned to row i (n_rows <= n_cols). */
 int32_t swk_lsap(const double *cost, int32_t n_rows, int32_t n_cols, int32_t *col4row);
 
+/* ---- ROI mask of a video (host side, no GPU, no context): SURVEY section 8f rank 3 -----------------------
+ * image_filtering.py:99-180, run once per video on its first frame.  PARITY UNPINNED (OpenCV 4.1.0 semantics restated:
+ * exact integer rules, see csrc/roi_mask.cpp).  Stage-level pieces first: */
+/* cv2.medianBlur (image_filtering.py:125-131): ksize x ksize per channel, BORDER_REPLICATE; src/dst [H][W][channels] */
+int32_t swk_median_blur_u8(const uint8_t *src, int32_t H, int32_t W, int32_t channels, int32_t ksize, uint8_t *dst);
+/* cv2.threshold(image, 0, 255, THRESH_BINARY + THRESH_OTSU) (image_filtering.py:143-151): dst (optional) = src > t ? 255 : 0,
+ * *thresh (optional) = Otsu's threshold t */
+int32_t swk_otsu_threshold_u8(const uint8_t *src, int64_t count, uint8_t *dst, int32_t *thresh);
+/* cv2.Canny(image, low, high) (image_filtering.py:154-159), aperture 3, L1 gradient */
+int32_t swk_canny_u8(const uint8_t *src, int32_t H, int32_t W, int32_t low, int32_t high, uint8_t *dst);
+/* cv2.dilate(image, ones((N, 1)), anchor=(0, 0)) (image_filtering.py:162-170): edges grow upwards by N - 1 rows */
+int32_t swk_dilate_up_u8(const uint8_t *src, int32_t H, int32_t W, int32_t N, uint8_t *dst);
+/* generate_regions (image_filtering.py:20-28): frame = first BGR frame [H][W][3] with row_stride bytes per row,
+ * corners = {x1, y1, x2, y2} of the chimney's top edge.  Writes crop_region = {x0, y0, x1, y1} (generate_crop_region)
+ * and the ROI mask, uint8 0 / 255, [y1 - y0][x1 - x0] (mask_capacity bytes available).  SWK_ERR_ARG when a region
+ * leaves the frame. */
+int32_t swk_roi_mask(const uint8_t *frame, int32_t H, int32_t W, int64_t row_stride, const int32_t corners[4],
+                     int32_t crop_region[4], uint8_t *mask, int64_t mask_capacity);
+
 /* ---- measurement hooks -----------------------------------------------------------
  * With profiling on, every kernel launch of swk_batch_run is bracketed by HIP events on
  * the context's stream; swk_prof_get returns accumulated device time and launch count per
@@ -235,9 +254,14 @@ int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *la
 int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
 /* Select the IALM pass kernel: 0 = auto (3, or 2 when A / E are requested), 1 = LDS/VALU kernel,
  * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per
- * element and iteration; produces the sparse u8 image and the iteration count, not A / E).
+ * element and iteration; produces the sparse u8 image and the iteration count, not A / E), instantiated per 16-frame
+ * block; 4 = the same pass instantiated per 4-frame k-step with a software-pipelined tile loop, 5 = 4 without the pipeline.
  * For A/B measurements only. */
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
+/* k-step-templated M-state pass (variants 4 / 5): bit 0 = the wave in the odd hardware slot of each SIMD runs at raised
+ * priority (breaks the lockstep of the two co-resident waves), bit 1 = it also starts late.  A/B knob; results never
+ * depend on it. */
+int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags);
 /* M-state pass only: the per-iteration stores of the sparse u8 image start once ||Z||_F < factor * tol * ||X||_F
  * (default 16; <= 0 = every pass).  A window that stops although the pass before its last iteration skipped the
  * stores makes the library run the batch again without the speculation, so results never depend on the factor;

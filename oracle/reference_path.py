@@ -208,31 +208,53 @@ def ialm(X, lmbda=0.01, tol=0.001, maxiter=100, return_iters=False):
     return A, E
 
 
+DEAD_EIG = 1e-13          # eigenvalues of M^T M below DEAD_EIG * lambda_max are zero singular directions
+
+
 def ialm_defined(X, lmbda=0.01, tol=0.001, maxiter=100, return_iters=False):
     """ialm() with the one behaviour the reference leaves to LAPACK made explicit.
 
-    The trailing window of a video is padded with all-zero "null" frames
-    (io_video.py:40-44) which do enter rpca().  A zero column gives the SVD a zero
-    singular value whose left vector is arbitrary, and the always-full `svp` (:285)
-    turns it into -(1/mu)*u*e_j^T: LAPACK-dependent garbage that leaks into the real
-    columns from iteration 2 on (measured: numpy 1.26 vs 2.2 disagree by 1.4 grey levels
-    on tests/golden/ialm_64x96x21_null5).  Defined behaviour used by this project: all-zero
-    columns are excluded from the decomposition (equivalently: zero singular directions get
-    a zero, not -1/mu, weight) and their A and E columns are 0.  Windows without zero
-    columns are untouched, so this is the reference's algorithm wherever the reference is
-    reproducible at all.
+    The last window of every video is rank deficient: it is padded with all-zero "null" frames (io_video.py:40-44),
+    and before them comes one DUPLICATE of the last real frame (the range test of get_frame is inclusive, so the
+    frame one past the end is requested once and served by the re-deliver-the-last-good-frame fallback,
+    io_video.py:40,51-53).  Both enter rpca().  A zero singular value has an arbitrary left vector u, and the
+    always-full `svp` (:285) turns it into the term -(1/mu) u v^T of A: LAPACK-dependent garbage of hundreds of grey
+    levels that leaks into every frame of the window from iteration 2 on (measured: numpy 1.26 and 2.2 disagree by
+    up to 2 grey levels on 3 % of the pixels of tests/golden/ialm_64x96x21_null5).
+
+    Defined behaviour of this project (oracle and HIP path alike): a singular direction of M whose sigma^2 is below
+    DEAD_EIG * sigma_max^2 is a ZERO direction and contributes nothing to A (its weight is 0 instead of
+    sigma - 1/mu).  For all-zero columns that is the same as leaving them out of the decomposition (their A and E stay
+    0); for duplicated columns the two copies share one decomposition.  Windows of full rank never meet the rule, so
+    this is the reference's algorithm wherever the reference is reproducible at all.
     """
     X = np.asarray(X)
-    live = np.flatnonzero(X.any(axis=0))
-    if live.size == X.shape[1]:
-        return ialm(X, lmbda, tol, maxiter, return_iters)
-    A = np.zeros(X.shape)
-    E = np.zeros(X.shape)
+    flat = X.ravel()
+    two_norm = np.linalg.norm(flat, 2)                       # :269
+    if two_norm == 0:                                         # nothing to decompose (the reference would divide by zero)
+        z = np.zeros(X.shape)
+        return (z, z.copy(), 0) if return_iters else (z, z.copy())
+    inf_norm = np.linalg.norm(flat, np.inf) / lmbda           # :270
+    scale = np.max([two_norm, inf_norm])                      # :271
+    Y = X / scale                                             # :272
+    A = np.zeros(Y.shape)
+    x_fro = np.linalg.norm(X, 'fro')                          # :275
+    mu = 1.25 / two_norm                                      # :276
     k = 0
-    if live.size:
-        a, e, k = ialm(X[:, live], lmbda, tol, maxiter, True)
-        A[:, live] = a
-        E[:, live] = e
+    null_cols = ~X.any(axis=0)
+    while True:
+        raw = X - A + (1 / mu) * Y                            # :282
+        E = np.maximum(raw - lmbda / mu, 0) + np.minimum(raw + lmbda / mu, 0)   # :283
+        U, S, Vt = np.linalg.svd(X - E + (1 / mu) * Y, full_matrices=False)     # :284
+        w = np.where(S * S > DEAD_EIG * S[0] * S[0], S - 1 / mu, 0.0)            # :285-290 with the zero-direction rule
+        A = np.dot(U * w, Vt)
+        A[:, null_cols] = 0.0                                 # exactly, not to rounding: a null frame stays out
+        Z = X - A - E                                         # :293
+        Y = Y + mu * Z                                        # :294
+        mu = mu * 1.5                                         # :295
+        k += 1
+        if (np.linalg.norm(Z, 'fro') / x_fro) < tol or k >= maxiter:   # :297
+            break
     return (A, E, k) if return_iters else (A, E)
 
 

@@ -92,11 +92,17 @@ _SIGS = {
     "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_median_blur_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_otsu_threshold_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_canny_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_dilate_up_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_roi_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_set_pass_tuning": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_method": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
@@ -213,6 +219,9 @@ class Context:
 
     def set_ialm_variant(self, variant):
         self._check(self._lib.swk_set_ialm_variant(self._h, int(variant)))
+
+    def set_pass_tuning(self, flags):
+        self._check(self._lib.swk_set_pass_tuning(self._h, int(flags)))
 
     def set_sparse_speculation(self, factor):
         self._check(self._lib.swk_set_sparse_speculation(self._h, float(factor)))
@@ -428,6 +437,59 @@ def lsap(cost):
     if rc:
         raise SwkError("swk_lsap failed (%d)" % rc)
     return out
+
+
+# ---- ROI mask of a video (host side, no GPU): image_filtering.py:99-180 ----
+def _host_call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc:
+        raise SwkError("%s failed (%d)" % (name, rc))
+
+
+def median_blur_u8(image, ksize):
+    a = np.ascontiguousarray(image, np.uint8)
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    out = np.empty_like(a)
+    _host_call("swk_median_blur_u8", _ptr(a), a.shape[0], a.shape[1], ch, int(ksize), _ptr(out))
+    return out
+
+
+def otsu_threshold_u8(image):
+    """(threshold, binary image): cv2.threshold(image, 0, 255, THRESH_BINARY + THRESH_OTSU)."""
+    a = np.ascontiguousarray(image, np.uint8)
+    out = np.empty_like(a)
+    t = ctypes.c_int32(0)
+    _host_call("swk_otsu_threshold_u8", _ptr(a), a.size, _ptr(out), ctypes.byref(t))
+    return t.value, out
+
+
+def canny_u8(image, low, high):
+    a = np.ascontiguousarray(image, np.uint8)
+    out = np.empty_like(a)
+    _host_call("swk_canny_u8", _ptr(a), a.shape[0], a.shape[1], int(low), int(high), _ptr(out))
+    return out
+
+
+def dilate_up_u8(image, N):
+    a = np.ascontiguousarray(image, np.uint8)
+    out = np.empty_like(a)
+    _host_call("swk_dilate_up_u8", _ptr(a), a.shape[0], a.shape[1], int(N), _ptr(out))
+    return out
+
+
+def roi_mask(frame, corners):
+    """swk_roi_mask: (crop_region [(x0, y0), (x1, y1)], mask uint8 (Hc, Wc)) from the first BGR frame and the two
+    chimney corners ((x1, y1), (x2, y2))."""
+    if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3 or frame.strides[2] != 1 or frame.strides[1] != 3:
+        frame = np.ascontiguousarray(frame, np.uint8)
+    c = np.array([corners[0][0], corners[0][1], corners[1][0], corners[1][1]], np.int32)
+    crop = np.zeros(4, np.int32)
+    left, right = min(c[0], c[2]), max(c[0], c[2])
+    width = int(right - left)
+    hc, wc = int(0.5 * width) + int(0.125 * width), width + 2 * int(0.125 * width)
+    mask = np.empty((max(hc, 1), max(wc, 1)), np.uint8)
+    _host_call("swk_roi_mask", _ptr(frame), frame.shape[0], frame.shape[1], frame.strides[0], _ptr(c), _ptr(crop), _ptr(mask), mask.size)
+    return [(int(crop[0]), int(crop[1])), (int(crop[2]), int(crop[3]))], mask
 
 
 _default_ctx = {}

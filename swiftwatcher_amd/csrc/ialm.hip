@@ -295,8 +295,9 @@ bool ialm_v2_supported(int n);
 
 void launch_ialm_pass_v3(hipStream_t s, const IalmBuffers &b, int mode, int k);
 
-void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k)
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k, int tune)
 {
+    if (variant >= 4) { launch_ialm_pass_m(s, b, mode, k, tune, variant == 4); return; }
     if (variant == 3) { launch_ialm_pass_v3(s, b, mode, k); return; }
     if (variant == 2) { launch_ialm_pass_v2(s, b, mode); return; }
     const bool we = b.E != nullptr;

@@ -1,0 +1,340 @@
+// IALM streaming pass on the f64 matrix cores, M-state formulation (see ialm_mfma.hip for the derivation: with
+// A_k = M_k B_k the multiplier update collapses to Y_k = mu_{k-1} (M_k - A_k), so M alone is carried between passes),
+// instantiated per NUMBER OF K-STEPS NK = ceil(n / 4) instead of per 16-frame block:
+//
+//   * a window of n frames moves 4 NK frame rows (n rounded up to 4, not to 16): the CLI's queue of 21 frames runs
+//     6 k-steps, 12 + 12 MFMAs per 16-pixel tile and 24 rows of state instead of 8, 16 + 12 and 32;
+//     n = 49 streams 52 rows instead of 64.  Rows n .. 4 NK - 1 read X = 0 through the buffer range check, stay
+//     exactly zero in M and U, and their sparse-image stores fall outside the buffer and are dropped.
+//   * the tile loop is software-pipelined: the next tile's loads are issued after the current tile's element-wise
+//     part, where its X / M / U registers are dead, and before its Gram phase, which only needs the LDS tile and the
+//     accumulators -- the loads fly under 12..40 MFMAs instead of being waited for at the top of the next tile.
+//   * the two waves that share a SIMD run the same program on equal tiles and fall into LOCKSTEP (measured on the
+//     block-templated kernel: matrix pipe 61 % busy, waves 60 % of their time stalled on issue, matrix and vector
+//     phases of the two waves never overlapping): one of the two (odd hardware wave slot) runs at raised priority, so
+//     it keeps the matrix pipe whenever it wants it and the other fills the gaps -- their phases drift apart for good.
+//
+// Register layout, LDS tiles, buffer addressing and arithmetic order are those of k_ialm_pass_v3 (ialm_mfma.hip).
+#include "swk_internal.h"
+
+namespace swk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned kOob = 0x80000000u;        // a byte offset past every buffer: loads give 0, stores are dropped
+constexpr float kUScale = 1.0f / 128.0f, kUUnscale = 128.0f;      // U travels as binary16 of U / 128 (ialm_mfma.hip)
+
+__device__ __forceinline__ double shrink2(double raw, double thr)
+{
+    return fmax(raw - thr, 0.0) + fmin(raw + thr, 0.0);          // image_filtering.py:283
+}
+__device__ __forceinline__ int sparse_u8b(double e)
+{
+    double v = -e;                                                // :244
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);                 // :245
+    return (int)(uint8_t)v;
+}
+__device__ __forceinline__ double buf_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ int buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st8(int v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff, soff, 0);
+}
+__device__ __forceinline__ float buf_ld16h(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const unsigned short bits = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    return (float)__builtin_bit_cast(_Float16, bits) * kUUnscale;
+}
+__device__ __forceinline__ void buf_st16h(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const _Float16 h = (_Float16)(v * kUScale);
+    __builtin_amdgcn_raw_buffer_store_b16((short)__builtin_bit_cast(unsigned short, h), r, voff, soff, 0);
+}
+
+template <int NK>
+struct MCfg {
+    static constexpr int NB = (NK + 3) / 4;                        // 16-frame output blocks
+    static constexpr int NPAD = 16 * NB;
+    static constexpr int BP = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;   // LDS pitch of B: rows 32 banks apart
+    static constexpr int TP = 17;                                  // LDS pitch of the transpose tile
+    static constexpr int NPAIR = NB * (NB + 1) / 2;
+    static constexpr size_t lds_bytes = (size_t)(NPAD * BP + 4 * NPAD * TP) * sizeof(double);
+};
+
+constexpr unsigned ROWSTEP = 128u;           // (4 t) * ROWSTEP = t * 512 elements: one chunk of M / U per k-step
+
+}  // namespace
+
+// tune: bit 0 = raised priority for the wave in the odd hardware slot of its SIMD, bit 1 = that wave also starts
+// half a tile late (A/B knobs; results do not depend on them)
+template <int NK, int MODE, bool PIPE>
+__global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, int tune)
+{
+    using C = MCfg<NK>;
+    constexpr int NB = C::NB, NPAD = C::NPAD, BP = C::BP, TP = C::TP;
+    extern __shared__ double lds[];
+    double *sB = lds;                                             // [NPAD][BP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *sT = lds + NPAD * BP + wave * (NPAD * TP);           // this wave's [NPAD][TP]
+    const int w = blockIdx.y;
+    const IalmWin &st = b.win[w];
+    if (st.done) return;
+    if (MODE == 0 && st.int_gram) return;        // the start pass's only product already came from k_gram_u8
+    if (tune & 3) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_ID.wave_id: this wave's slot on its SIMD
+        if (slot & 1u) {
+            if (tune & 1) __builtin_amdgcn_s_setprio(1);
+            if (tune & 2) { __builtin_amdgcn_s_sleep(64); }
+        }
+    }
+    const bool ws = st.ws != 0;                  // sparse-image stores on for this pass (k_ialm_small decides)
+    const bool ru = st.ru != 0, wu = st.wu != 0; // all of U read (full ||Z||) / written in this pass; else frames 0..3 only
+    const int n = b.n, P = b.P;
+    const unsigned P32 = (unsigned)P;
+    const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
+    const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
+    const double dual = st.dual_norm;
+    const int felems = b.fpad * (int)b.pstride;                   // b.fpad == 4 NK
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)((sel ? b.Salt : b.S) + (int64_t)w * n * P), 0, n * P, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)(b.A + (int64_t)w * b.fpad * b.pstride), 0, felems * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)(b.U + (int64_t)w * b.fpad * b.pstride), 0, felems * 2, 0x00020000);
+
+    // Y0 = X / dual_norm (:272) for the first two passes: one Newton step on x * (1/dual), the correctly rounded quotient
+    const double rdual = 1.0 / dual;
+    auto y0_of = [&](double x) {
+        const double q = x * rdual;
+        return __builtin_fma(__builtin_fma(-q, dual, x), rdual, q);
+    };
+    if (MODE != 0) {
+        const double *Bm = b.Bm + (int64_t)w * n * n;
+        for (int i = tid; i < NPAD * NPAD; i += 256) {
+            const int k = i / NPAD, c = i % NPAD;
+            sB[k * BP + c] = (k < n && c < n) ? Bm[k * n + c] : 0.0;
+        }
+    }
+    // frame rows 4 NK .. NPAD - 1 of the transpose tile are never written: they must read as zeros in the Gram phase
+    for (int i = lane; i < (NPAD - 4 * NK) * TP; i += 64) sT[4 * NK * TP + i] = 0.0;
+    __syncthreads();
+
+    const int pl = lane & 15, fr0 = lane >> 4;
+    d4 G[C::NPAIR];
+#pragma unroll
+    for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double zz = 0.0, zz0 = 0.0;                  // sum of z^2 over frames >= 4 / frames 0..3
+
+    // a block owns groups of 8 consecutive tiles = 128 pixels (every 128-byte line of the u8 planes is touched by ONE
+    // workgroup), two tiles per wave back to back; the valid tiles of a wave are a prefix of its sequence
+    const int ntiles = (P + 15) >> 4;
+    const int nsteps = 2 * ((((ntiles + 7) >> 3) - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    auto tile_of = [&](int it) { return ((int)blockIdx.x + (it >> 1) * (int)gridDim.x) * 8 + wave * 2 + (it & 1); };
+
+    int xi[NK];
+    double mv[NK];
+    float uf[NK];
+    unsigned vo8, vo2, vo1;                      // per-lane byte offsets of the current tile: f64 state, f16 copy of Y/mu, u8 planes
+    auto offsets = [&](int tile, unsigned &o8, unsigned &o2, unsigned &o1) {
+        const unsigned p = (unsigned)(tile * 16 + pl);
+        const bool pvalid = tile < ntiles && p < P32;
+        // M and U are private to this kernel: [group of 128 pixels][k-step t][tile 0..7][frame 4t + 0..3][16 px]
+        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)b.fpad * 128u + ((unsigned)tile & 7u) * 64u + (unsigned)fr0 * 16u + (unsigned)pl;
+        o8 = pvalid ? ge * 8u : kOob;
+        o2 = pvalid ? ge * 2u : kOob;
+        o1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;
+    };
+    auto load_tile = [&](unsigned o8, unsigned o2, unsigned o1) {
+        const unsigned o2r = ru ? o2 : kOob;
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            xi[t] = buf_ld8(rX, o1, (unsigned)(4 * t) * P32);
+            if (MODE == 2) {
+                mv[t] = buf_ld64(rM, o8, (unsigned)(4 * t) * ROWSTEP * 8u);
+                uf[t] = buf_ld16h(rU, t == 0 ? o2 : o2r, (unsigned)(4 * t) * ROWSTEP * 2u);
+            }
+        }
+    };
+
+    int tile = nsteps > 0 ? tile_of(0) : ntiles;
+    offsets(tile, vo8, vo2, vo1);
+    load_tile(vo8, vo2, vo1);
+    for (int it = 0; it < nsteps && tile < ntiles; ++it) {
+        const unsigned vo1s = ws ? vo1 : kOob;
+        const unsigned vo2w = wu ? vo2 : kOob;
+        if (MODE == 1) {
+            // first iteration: A_0 = 0 (:273) and Y_0 = X / dual (:272), so M_1 is a function of X alone
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                const double x = (double)xi[t];
+                const double u0 = inv_mu * y0_of(x);
+                const double e = shrink2(x + u0, thr);                             // :282-283
+                mv[t] = (x - e) + u0;                                              // :284
+            }
+        }
+        // ---- A_k^T = B^T M_k^T on the matrix cores, two out-frame blocks at a time (two independent accumulator
+        //      chains), then Z, Y, the start of the next iteration and the stores ----
+#pragma unroll
+        for (int bq0 = 0; bq0 < NB; bq0 += 2) {
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            if (MODE != 0) {
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (bq0 + h < NB) {
+                            const double bop = sB[(4 * t + fr0) * BP + 16 * (bq0 + h) + pl];
+                            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc[h], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (bq0 + h >= NB) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * (bq0 + h) + r;
+                    if (t >= NK) continue;
+                    const double x = (double)xi[t];
+                    double a_new, y;
+                    if (MODE == 0) {
+                        a_new = 0.0;
+                        y = y0_of(x);
+                    } else {
+                        a_new = acc[h][r];                                             // :290
+                        const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}
+                        const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * y0_of(x);
+                        const double z = pk - uprev;                                   // :293
+                        if (t == 0) zz0 += z * z; else zz += z * z;
+                        y = mu * pk;                                                   // :294
+                    }
+                    const double u = inv_mu2 * y;
+                    const double e2 = shrink2((x - a_new) + u, thr2);
+                    const double m2 = (x - e2) + u;
+                    sT[(4 * t + fr0) * TP + pl] = m2;
+                    if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
+                        buf_st64(m2, rM, vo8, (unsigned)(4 * t) * ROWSTEP * 8u);
+                        buf_st16h((float)u, rU, t == 0 ? vo2 : vo2w, (unsigned)(4 * t) * ROWSTEP * 2u);
+                    }
+                    buf_st8(sparse_u8b(e2), rS, vo1s, (unsigned)(4 * t) * P32);
+                }
+            }
+        }
+        // ---- the next tile's loads go out here: xi / mv / uf are dead, the Gram phase below needs none of them ----
+        const int tile_n = it + 1 < nsteps ? tile_of(it + 1) : ntiles;
+        unsigned n8, n2, n1;
+        offsets(tile_n, n8, n2, n1);
+        if (PIPE) load_tile(n8, n2, n1);
+        // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            double tr[NB];
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) tr[fb] = sT[(16 * fb + pl) * TP + 4 * g + fr0];
+            int pair = 0;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB; ++jb) {
+                    G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ib], tr[jb], G[pair], 0, 0, 0);
+                    ++pair;
+                }
+        }
+        if (!PIPE) load_tile(n8, n2, n1);
+        tile = tile_n; vo8 = n8; vo2 = n2; vo1 = n1;
+    }
+
+    // ---- block-level, fixed-order combination of the four waves' Gram accumulators ----
+    __syncthreads();
+    double *sG = lds;                           // reuse: [NPAD][NPAD] <= NPAD * BP + 4 * NPAD * TP
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+            int pair = 0;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB; ++jb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ib + fr0 + 4 * r, j = 16 * jb + pl;
+                        if (wv == 0) sG[i * NPAD + j] = G[pair][r];
+                        else sG[i * NPAD + j] += G[pair][r];
+                    }
+                    ++pair;
+                }
+        }
+        __syncthreads();
+    }
+    double *gp = b.gpart + ((int64_t)w * b.nblk + blockIdx.x) * n * n;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        if ((i >> 4) <= (j >> 4)) gp[idx] = sG[i * NPAD + j];
+    }
+    if (MODE != 0) {
+        zz = zz0 + ((MODE == 1 || ru) ? zz : 0.0);           // without all of U only the first four frames count
+        for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
+        __syncthreads();
+        if (lane == 0) lds[NPAD * NPAD + wave] = zz;
+        __syncthreads();
+        if (tid == 0)
+            b.zzpart[(int64_t)w * b.nblk + blockIdx.x] =
+                ((lds[NPAD * NPAD] + lds[NPAD * NPAD + 1]) + lds[NPAD * NPAD + 2]) + lds[NPAD * NPAD + 3];
+    }
+}
+
+template <int NK, int MODE, bool PIPE>
+static void launch_m_one(hipStream_t s, const IalmBuffers &b, int sel, int tune)
+{
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_m<NK, MODE, PIPE>, MCfg<NK>::lds_bytes, attr_mask)) return;
+    hipLaunchKernelGGL((k_ialm_pass_m<NK, MODE, PIPE>), dim3(b.nblk, b.nwin), dim3(256), MCfg<NK>::lds_bytes, s, b, sel, tune);
+    note_launch();
+}
+
+template <int NK>
+static void launch_m_nk(hipStream_t s, const IalmBuffers &b, int mode, int sel, int tune, bool pipe)
+{
+    if (mode == 0) { if (pipe) launch_m_one<NK, 0, true>(s, b, sel, tune); else launch_m_one<NK, 0, false>(s, b, sel, tune); }
+    else if (mode == 1) { if (pipe) launch_m_one<NK, 1, true>(s, b, sel, tune); else launch_m_one<NK, 1, false>(s, b, sel, tune); }
+    else { if (pipe) launch_m_one<NK, 2, true>(s, b, sel, tune); else launch_m_one<NK, 2, false>(s, b, sel, tune); }
+}
+
+// frames per window -> planes of M / U state per window for this kernel
+int ialm_mstate_fpad(int n) { return (n + 3) & ~3; }
+
+void launch_ialm_pass_m(hipStream_t s, const IalmBuffers &b, int mode, int k, int tune, bool pipe)
+{
+    const int sel = k & 1;
+    switch ((b.n + 3) / 4) {
+    case 1: launch_m_nk<1>(s, b, mode, sel, tune, pipe); break;
+    case 2: launch_m_nk<2>(s, b, mode, sel, tune, pipe); break;
+    case 3: launch_m_nk<3>(s, b, mode, sel, tune, pipe); break;
+    case 4: launch_m_nk<4>(s, b, mode, sel, tune, pipe); break;
+    case 5: launch_m_nk<5>(s, b, mode, sel, tune, pipe); break;
+    case 6: launch_m_nk<6>(s, b, mode, sel, tune, pipe); break;
+    case 7: launch_m_nk<7>(s, b, mode, sel, tune, pipe); break;
+    case 8: launch_m_nk<8>(s, b, mode, sel, tune, pipe); break;
+    case 9: launch_m_nk<9>(s, b, mode, sel, tune, pipe); break;
+    case 10: launch_m_nk<10>(s, b, mode, sel, tune, pipe); break;
+    case 11: launch_m_nk<11>(s, b, mode, sel, tune, pipe); break;
+    case 12: launch_m_nk<12>(s, b, mode, sel, tune, pipe); break;
+    case 13: launch_m_nk<13>(s, b, mode, sel, tune, pipe); break;
+    case 14: launch_m_nk<14>(s, b, mode, sel, tune, pipe); break;
+    case 15: launch_m_nk<15>(s, b, mode, sel, tune, pipe); break;
+    default: launch_m_nk<16>(s, b, mode, sel, tune, pipe); break;
+    }
+}
+
+}  // namespace swk

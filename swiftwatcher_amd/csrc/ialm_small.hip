@@ -358,6 +358,24 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             if (res2 < 1e-8 && alpha == 1.0) final_step = true;              // ||I - ZY|| < 1e-4: two more plain steps reach 1e-16
         }
         if (converged) {
+            // A (numerically) zero eigenvalue that is not a zero row of G -- the duplicated last frame of every video
+            // (io_video.py:51-53) makes two columns of M equal -- converges here to a weight of 1e6 and more on a
+            // direction made of rounding noise.  ||Z||_F^2 = sum s / lambda_i gives it away: such a matrix goes to the
+            // Jacobi solver, which gives eigenvalues below 1e-13 lambda_max the weight 0 (the project's defined
+            // behaviour for zero singular directions).
+            double zacc = 0.0;
+            for (int idx = tid; idx < n * n; idx += kSmallThreads) { const double v = Z[(idx / n) * PITCH + idx % n]; zacc += v * v; }
+            __syncthreads();
+            red[tid] = zacc;
+            __syncthreads();
+            for (int s = kSmallThreads / 2; s; s >>= 1) {
+                if (tid < s) red[tid] += red[tid + s];
+                __syncthreads();
+            }
+            if (!(red[0] < 1e11)) converged = false;
+            __syncthreads();
+        }
+        if (converged) {
             const double wscale = 1.0 / sqrt(sc);
             for (int idx = tid; idx < n * n; idx += kSmallThreads) {
                 const int i = idx / n, j = idx - i * n;

@@ -46,6 +46,7 @@ struct swk_ctx {
     int64_t prof_n[SWK_K_COUNT] = {0};
     int64_t window_iters = 0;
     int ialm_variant = 0;
+    int pass_tune = 0;             // k-step-templated pass: bit 0 priority, bit 1 stagger for the odd hardware wave slot
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
@@ -256,7 +257,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = ctx->ialm_variant;
     if (variant == 0) variant = 3;
-    if (variant == 3 && (want_A || want_E)) variant = 2;
+    if (variant >= 3 && (want_A || want_E)) variant = 2;
+    const bool mstate = variant >= 3;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
     // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
     // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
     // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
@@ -266,7 +268,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
     b.nred = b.nblk > 4 ? 1 : b.nblk;       // several slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
-    b.fpad = (n + 15) & ~15;
+    b.fpad = variant >= 4 ? ialm_mstate_fpad(n) : (n + 15) & ~15;
     ctx->pstride = b.pstride;
     ctx->fpad = b.fpad;
     if ((int64_t)b.fpad * b.pstride >= (1ll << 28)) return fail(ctx, SWK_ERR_ARG, "window too large: frames x ROI pixels must stay below 2^28");
@@ -274,7 +276,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     const size_t felems = (size_t)nwin * b.fpad * b.pstride;
     NEED(ctx, SL_A, felems * 8, b.A);
     NEED(ctx, SL_Y, felems * 8, b.Y);
-    if (variant == 3) {
+    if (mstate) {
         b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
         b.spec = (speculate && ctx->sparse_backoff == 0) ? ctx->sparse_spec : 0.0;
         b.nspec = (speculate && ctx->norm_backoff == 0) ? ctx->norm_spec : 0.0;
@@ -295,7 +297,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     HIPCHK(ctx, hipMemsetAsync(b.win, 0, (size_t)nwin * sizeof(IalmWin), s));
     HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16 * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(dS, 0, elems, s));
-    if (variant == 3) {
+    if (mstate) {
         HIPCHK(ctx, hipMemsetAsync(b.Salt, 0, elems, s));
     } else {
         // a window that stops before writing A (all-zero input) must still read back zeros
@@ -344,13 +346,13 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     for (int g = 0; g < ngroups; ++g) {
         // window statistics (||X||_F, max) and, for the M-state pass, the first Gram matrix in the same read of X
         // on the integer matrix cores; windows it does not cover get the f64 start pass below
-        grp[g].b.use_gram8 = (variant == 3 && ctx->use_gram8 && gram_u8_supported(grp[g].b)) ? 1 : 0;
+        grp[g].b.use_gram8 = (mstate && ctx->use_gram8 && gram_u8_supported(grp[g].b)) ? 1 : 0;
         { Timed t(ctx, SWK_K_IALM_STATS);
           if (grp[g].b.use_gram8) launch_gram_u8(s, grp[g].b); else launch_ialm_stats(s, grp[g].b);
           launch_ialm_init(s, grp[g].b, lmbda); }
         // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
         // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
-        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0); }
+        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0, ctx->pass_tune); }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
         { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]);
@@ -373,7 +375,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             if (k > maxiter) { gr.finished = true; continue; }
             any = true;
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
-            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant, k); }
+            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant, k, ctx->pass_tune); }
             HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
             hipStream_t gs = ctx->gstream[g];
             HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
@@ -390,8 +392,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     }
     // everything after the IALM runs on the main stream: join the side streams
     for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
-    if (variant == 3) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
-    if (variant == 3 && (b.spec > 0.0 || b.nspec > 0.0)) {
+    if (mstate) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
+    if (mstate && (b.spec > 0.0 || b.nspec > 0.0)) {
         // did any window stop right after a pass that had its sparse-image stores switched off?
         std::vector<IalmWin> hw(nwin);
         HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
@@ -552,8 +554,15 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters)
 }
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 3) return SWK_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 5) return SWK_ERR_ARG;
     ctx->ialm_variant = variant;
+    return SWK_OK;
+}
+
+int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags)
+{
+    if (!ctx || flags < 0 || flags > 3) return SWK_ERR_ARG;
+    ctx->pass_tune = flags;
     return SWK_OK;
 }
 

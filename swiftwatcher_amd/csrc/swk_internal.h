@@ -72,7 +72,10 @@ struct IalmBuffers {
 void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
 // k = iteration number of the pass (0 = Gram-only start pass); variant 3 = M-state pass (no A/E outputs)
-void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k);
+void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k, int tune = 0);
+// ialm_mstate.hip: the M-state pass instantiated per k-step count
+void launch_ialm_pass_m(hipStream_t s, const IalmBuffers &b, int mode, int k, int tune, bool pipe);
+int  ialm_mstate_fpad(int n);
 void launch_select_sparse(hipStream_t s, const IalmBuffers &b);
 // method: 0 = Newton-Schulz on the f64 matrix cores (Jacobi only as fallback), 1 = cyclic Jacobi
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);

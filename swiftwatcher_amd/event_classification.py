@@ -35,17 +35,19 @@ def compute_mode(angles):
 
 
 def classify_events(events):
-    """:47-117.  Returns a dict of parallel lists over the events that survive filter_false_angles
-    (angles that are exact multiples of 15 degrees are dropped, :86-100):
+    """:47-117.  Returns a dict of parallel lists over the events that survive filter_false_angles:
     framenumber, timestamp, angle, label (1 = swift entered: mode-30 < angle <= mode+30, the (a, b] bins of
-    pandas.cut), plus 'mode'."""
+    pandas.cut), plus 'mode'.
+
+    filter_false_angles (:86-100) drops by INDEX LABEL: `df.drop(df[angle % 15 == 0].index)` removes every row whose
+    (timestamp, framenumber) equals that of an event with an exact multiple of 15 degrees -- so an event that ends on the
+    same frame as such an event goes with it.  Reproduced (the reference's own CSV fixtures need it)."""
     rows = []
     for event in events:
         centroids = [s.centroid for s in event]
-        angle = compute_angle(centroids)
-        if angle % 15 == 0:
-            continue
-        rows.append((event[-1].parent_frame_number, event[-1].parent_timestamp, angle))
+        rows.append((event[-1].parent_frame_number, event[-1].parent_timestamp, compute_angle(centroids)))
+    dropped = {(r[1], r[0]) for r in rows if r[2] % 15 == 0}
+    rows = [r for r in rows if (r[1], r[0]) not in dropped]
     angles = [r[2] for r in rows]
     mode = compute_mode(angles)
     lo, hi = mode - 30, mode + 30

@@ -4,8 +4,9 @@ return types, every pixel operation running as a HIP kernel on the MI355X throug
 libswk.so (ctypes, swiftwatcher_amd/_lib.py).  No OpenCV / SciPy / scikit-image involved
 and no CPU fallback: without the GPU library these functions raise SwkError.
 
-The ROI-mask section of the reference file (generate_roi_mask and friends, lines 99-180)
-runs once per video, feeds the tracker, and is out of scope.
+The ROI-mask section of the reference file (generate_regions / generate_roi_mask and friends, lines 20-28 and
+99-180) runs once per video on a few hundred by a hundred pixels and feeds the host-side tracker: it is host C++ in
+the same library (csrc/roi_mask.cpp), same function names here.
 """
 import math
 
@@ -45,6 +46,56 @@ def generate_roi_crop_region(corners):
 def crop_frame(frame, crop_region):
     """image_filtering.py:199-203: a view, like the reference."""
     return frame[crop_region[0][1]:crop_region[1][1], crop_region[0][0]:crop_region[1][0]]
+
+
+###############################################################################
+# ROI mask -- once per video, host C++ (image_filtering.py:20-28, 99-180); PARITY UNPINNED (cv2)
+###############################################################################
+
+
+def generate_regions(first_frame, corners):
+    """image_filtering.py:20-28: (crop_region, roi_mask, resize_dim) for a video, from its first frame and the two
+    chimney corners.  resize_dim is handed through like in the reference (its resize step is commented out there)."""
+    resize_dim = (300, 150)
+    crop_region, roi_mask = _lib.roi_mask(first_frame, corners)
+    return crop_region, roi_mask, resize_dim
+
+
+def generate_roi_mask(frame, corners, crop_region=None, resize_dim=None):
+    """image_filtering.py:99-122 (crop_region is recomputed from the corners, as generate_regions does)."""
+    return _lib.roi_mask(frame, corners)[1]
+
+
+def median_blur(image, kernel_size):
+    """image_filtering.py:125-131 (cv2.medianBlur)."""
+    return _lib.median_blur_u8(image, kernel_size)
+
+
+def split_bgr_channels(image):
+    """image_filtering.py:134-139 (cv2.split)."""
+    return (np.ascontiguousarray(image[:, :, 0]), np.ascontiguousarray(image[:, :, 1]), np.ascontiguousarray(image[:, :, 2]))
+
+
+def threshold_channel(image):
+    """image_filtering.py:142-151: Otsu's threshold, binary 0 / 255 output."""
+    return _lib.otsu_threshold_u8(image)[1]
+
+
+def detect_canny_edges(image):
+    """image_filtering.py:154-159: cv2.Canny(image, 0, 256)."""
+    return _lib.canny_u8(image, 0, 256)
+
+
+def dilate_upwards(image, N):
+    """image_filtering.py:162-170: N x 1 kernel anchored at its top, so edges only grow upwards."""
+    return _lib.dilate_up_u8(image, N)
+
+
+def create_mask(mask, frame_region, frame):
+    """image_filtering.py:173-181: the ROI-sized mask pasted into a blank single-channel image of the frame's size."""
+    out = np.zeros(frame.shape[:2], np.uint8)
+    out[frame_region[0][1]:frame_region[1][1], frame_region[0][0]:frame_region[1][0]] = mask
+    return out
 
 
 ###############################################################################

@@ -31,8 +31,10 @@ class ArrayReader:
         return frame
 
     def frame_number_to_timestamp(self, frame_number):
-        """:74-82: midnight today + frame_number / fps, rounded to microseconds."""
-        return self._midnight + datetime.timedelta(microseconds=round(frame_number / self.fps * 1e6))
+        """:74-82: midnight today + frame_number / fps, rounded to microseconds with pandas' own integer-nanosecond
+        arithmetic (io_data.frame_timestamp_ns), so the stamps join the exporter's per-frame table exactly."""
+        from .io_data import frame_timestamp_ns
+        return self._midnight + datetime.timedelta(microseconds=frame_timestamp_ns(frame_number, self.fps) // 1000)
 
     def get_frame(self, frame_number=None):
         if frame_number is None:

@@ -1,20 +1,28 @@
 """The reference's per-video loop (swift_counting_algorithm, __main__.py:56-100) over the MI355X segment path:
 read queue_size frames -> preprocess_queue + segment_queue (one GPU call) -> per popped frame: optional
-classifier, tracker step -> events -> swift count.  ROI-mask generation and CSV export stay with the caller
-(out of scope): crop_region and roi_mask are arguments; the reader is anything with the
-reference FrameReader's get_n_frames / total_frames (swiftwatcher_amd.io_frames.ArrayReader for decoded frames)."""
+classifier, tracker step -> events -> swift count.  The regions come from the chimney corners like in the reference
+(generate_regions on the first frame, __main__.py:62-63) or are handed in; the reader is anything with the
+reference FrameReader's read_frame / get_n_frames / total_frames (swiftwatcher_amd.io_frames.ArrayReader for decoded
+frames)."""
 from .data_structures import FrameQueue, segment_windows
 from .io_frames import ArrayReader
 from .segment_tracking import SegmentTracker
 from . import event_classification as ec
+from . import image_filtering as img
 
 
-def swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=21, classifier=None, min_seg_size=(24, 24),
-                             device=0, keep_stages=False, windows_per_call=1):
-    """Same call order as __main__.py:67-100.  Returns the tracker's detected events (lists of Segment objects,
+def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size=21, classifier=None, min_seg_size=(24, 24),
+                             device=0, keep_stages=False, windows_per_call=1, corners=None):
+    """Same call order as __main__.py:62-100.  corners = ((x1, y1), (x2, y2)) of the chimney's top edge: crop region
+    and ROI mask are then generated from the video's first frame (:62-63) instead of being passed in.  Returns the tracker's detected events (lists of Segment objects,
     the structure the reference hands to event classification).  windows_per_call > 1 reads that many queue-fuls
     ahead and segments (and classifies) them in one GPU call each; the tracker still sees the frames one by one in
     the reference's order, so the events are the same."""
+    if corners is not None:
+        first_frame = reader.read_frame(0, increment=False)                        # :62
+        crop_region, roi_mask, _ = img.generate_regions(first_frame, corners)      # :63
+    if crop_region is None or roi_mask is None:
+        raise ValueError("either corners or crop_region + roi_mask are needed")
     tracker = SegmentTracker(roi_mask)
     if windows_per_call > 1:
         # producer thread: reads ahead and segments (GPU call and array copies release the GIL);
@@ -66,7 +74,7 @@ def swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=21, class
     return tracker.detected_events
 
 
-def count_swifts(frames, crop_region, roi_mask, fps=30.0, **kw):
-    """Decoded frames (oldest first) -> (swift count, events)."""
+def count_swifts(frames, crop_region=None, roi_mask=None, fps=30.0, **kw):
+    """Decoded frames (oldest first) -> (swift count, events).  Regions either explicit or from corners=..."""
     events = swift_counting_algorithm(ArrayReader(frames, fps=fps), crop_region, roi_mask, **kw)
     return ec.count_swifts(events), events

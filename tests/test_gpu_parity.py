@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ATOL_AE = 1e-5
 
 
-@pytest.fixture(scope="module", params=[(0, 0), (2, 0), (1, 1), (2, 1)],
-                ids=["auto_pass+newton_schulz", "mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi"])
+@pytest.fixture(scope="module", params=[(0, 0), (2, 0), (1, 1), (2, 1), (3, 0)],
+                ids=["auto_pass+newton_schulz", "mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi",
+                     "block_templated_mstate_pass+newton_schulz"])
 def ctx(request):
     """Every test runs against the IALM pass kernels (0 = auto: the M-state MFMA pass, or the A/Y-state one when
     A / E are requested; 2 = A/Y-state MFMA pass; 1 = LDS/VALU) and both G^(-1/2) solvers (0 = Newton-Schulz on
@@ -301,6 +302,70 @@ def test_ialm_vs_oracle_and_null_frames(ctx, orc):
     # all-zero window: defined as zeros, zero iterations
     A, E, it = ctx.ialm(np.zeros((5, 300), np.uint8))
     assert it == 0 and not A.any() and not E.any()
+
+
+def test_mstate_pass_every_kstep_count(orc):
+    """The M-state pass is instantiated per k-step count NK = ceil(n / 4), 1..16: every NK (and n that are / are not
+    multiples of 4) on a ROI with a ragged last tile, the pipelined and the plain tile loop, with and without the
+    priority / stagger knobs -- all bit-identical to the block-templated kernel (itself checked against the oracle
+    throughout this file), and to the oracle directly for the CLI's queue of 21 and for n = 49."""
+    from swiftwatcher_amd import _lib, synthetic
+    cases = [(1, 120, 200), (3, 90, 130), (4, 90, 130), (5, 80, 120), (9, 64, 100), (13, 64, 90), (18, 50, 90), (21, 61, 93),
+             (26, 48, 80), (31, 48, 70), (36, 48, 70), (37, 48, 66), (45, 40, 70), (49, 40, 66), (52, 40, 60), (57, 40, 60),
+             (61, 36, 60), (64, 36, 58)]
+    ctxs = {}
+    for key, (variant, tune) in {"block": (3, 0), "pipe": (4, 0), "pipe+prio": (4, 1), "pipe+prio+stagger": (4, 3),
+                                 "plain": (5, 0), "plain+prio": (5, 1)}.items():
+        c = _lib.Context(0)
+        c.set_ialm_variant(variant)
+        c.set_pass_tuning(tune)
+        ctxs[key] = c
+    for n, Hc, Wc in cases:
+        roi = np.concatenate([synthetic.roi_window(900 + n + w, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
+                              for w in range(2)])
+        base = ctxs["block"].batch_run(roi, 2, n, stages=("rpca", "labels"))
+        for key, c in ctxs.items():
+            if key == "block":
+                continue
+            res = c.batch_run(roi, 2, n, stages=("rpca", "labels"))
+            np.testing.assert_array_equal(res["iters"], base["iters"], err_msg="%s n=%d" % (key, n))
+            np.testing.assert_array_equal(res["rpca"], base["rpca"], err_msg="%s n=%d" % (key, n))
+            np.testing.assert_array_equal(res["labels"], base["labels"], err_msg="%s n=%d" % (key, n))
+            assert res["segs"].tobytes() == base["segs"].tobytes()
+        if n in (21, 49):
+            for w in range(2):
+                ref = orc.window(np.ascontiguousarray(roi[w * n:(w + 1) * n]))
+                np.testing.assert_array_equal(base["rpca"][w * n:(w + 1) * n], ref["rpca"])
+    for c in ctxs.values():
+        c.close()
+
+
+def test_duplicated_last_frame_and_null_padding(ctx, orc):
+    """The last window of every video: real frames, ONE duplicate of the last real frame (io_video.py:51-53 re-delivers
+    it when the frame one past the end is requested) and null frames (io_video.py:40-44).  Two equal columns make M
+    rank deficient exactly like the zero columns do; the zero direction gets weight 0 (oracle.ialm_defined), whichever
+    solver finds it: Newton-Schulz has to notice and hand over to Jacobi."""
+    from swiftwatcher_amd import synthetic
+    for n, real, Hc, Wc in [(21, 8, 96, 128), (21, 20, 64, 96), (64, 30, 48, 80)]:
+        roi = synthetic.roi_window(700 + n + real, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
+        # queue order, newest first: [null ... null, duplicate, last real frame, older frames ...]
+        pad = n - real - 1
+        roi[:pad] = 0
+        roi[pad] = roi[pad + 1]
+        res = ctx.batch_run(roi, 1, n)
+        ref = orc.window(roi)
+        gray = ref["gray"].reshape(n, -1).T
+        assert int(res["iters"][0]) == orc.ialm_defined(gray, return_iters=True)[2]
+        for key in ("rpca", "opened", "labels"):
+            np.testing.assert_array_equal(res[key], ref[key], err_msg="%s n=%d real=%d" % (key, n, real))
+        for i in range(n):
+            assert _segs(res, i) == _orc_segs(ref["segments"][i])
+        assert not res["rpca"][:pad].any()
+        np.testing.assert_array_equal(res["rpca"][pad], res["rpca"][pad + 1])       # the two copies share one decomposition
+        A, E, it = ctx.ialm(gray.T.copy())
+        A0, E0 = orc.ialm_defined(gray)
+        np.testing.assert_allclose(A, A0, atol=ATOL_AE, rtol=0)
+        np.testing.assert_allclose(E, E0, atol=ATOL_AE, rtol=0)
 
 
 # ------------------------------------------------------------------ whole window
