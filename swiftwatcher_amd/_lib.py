@@ -110,6 +110,28 @@ _SIGS = {
 EXPORTS = sorted(_SIGS)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, like /opt/rocm's).  If libswk.so
+    is loaded first it pulls in the system runtime, torch then loads its bundled copy as a SECOND HIP runtime in the
+    process and sees no device (measured: torch.cuda.is_available() turns False).  Loading torch's copy first makes it
+    the process's one runtime: libswk's request for libamdhip64.so.7 binds to it by SONAME and a later `import torch`
+    finds its own file already mapped -- which is also what happens when torch is imported before this module.
+    torch itself is NOT imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libswk.so and type its entry points.  Raises SwkError when the library has not
     been built (python swiftwatcher_amd/csrc/build.py) -- never falls back to anything."""
@@ -119,6 +141,7 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise SwkError("libswk.so not built: run `python swiftwatcher_amd/csrc/build.py` "
                                "(there is no CPU fallback)")
+            _preload_torch_hip_runtime()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in _SIGS.items():
                 fn = getattr(lib, name)          # AttributeError = ABI mismatch, let it surface

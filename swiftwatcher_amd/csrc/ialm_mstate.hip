@@ -34,8 +34,8 @@ __device__ __forceinline__ double shrink2(double raw, double thr)
 __device__ __forceinline__ int sparse_u8b(double e)
 {
     double v = -e;                                                // :244
-    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);                 // :245
-    return (int)(uint8_t)v;
+    v = fmin(fmax(v, 0.0), 255.0);                               // :245
+    return (int)v;                                               // astype(uint8) truncates
 }
 __device__ __forceinline__ double buf_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
@@ -78,9 +78,158 @@ constexpr unsigned ROWSTEP = 128u;           // (4 t) * ROWSTEP = t * 512 elemen
 
 }  // namespace
 
+struct PassCtx {
+    __amdgpu_buffer_rsrc_t rX, rS, rM, rU;
+    double *sB, *sT;
+    double inv_mu, thr, inv_mu2, thr2, dual, rdual, ratio;
+    float ratio_f;
+    unsigned P32, fpad;
+    int pl, fr0, wave, ntiles, nsteps, bx, gx;
+};
+
+// The tile loop of one wave.  WS: this pass stores the sparse image; RU / WU: it reads / writes all of U (else frames 0..3).
+template <int NK, int MODE, bool WS, bool RU, bool WU>
+__device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::NPAIR], float &zz, float &zz0)
+{
+    using C = MCfg<NK>;
+    constexpr int NB = C::NB, BP = C::BP, TP = C::TP;
+    auto y0_of = [&](double x) {
+        const double q = x * cx.rdual;
+        return __builtin_fma(__builtin_fma(-q, cx.dual, x), cx.rdual, q);
+    };
+    auto tile_of = [&](int it) { return (cx.bx + (it >> 1) * cx.gx) * 8 + cx.wave * 2 + (it & 1); };
+    int xi[NK];
+    double mv[NK];
+    float uf[NK];
+    unsigned vo8, vo2, vo1;                      // per-lane byte offsets of the current tile: f64 state, f16 copy of Y/mu, u8 planes
+    auto offsets = [&](int tile, unsigned &o8, unsigned &o2, unsigned &o1) {
+        const unsigned p = (unsigned)(tile * 16 + cx.pl);
+        const bool pvalid = tile < cx.ntiles && p < cx.P32;
+        // M and U are private to this kernel: [group of 128 pixels][k-step t][tile 0..7][frame 4t + 0..3][16 px]
+        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)cx.fpad * 128u + ((unsigned)tile & 7u) * 64u + (unsigned)cx.fr0 * 16u + (unsigned)cx.pl;
+        o8 = pvalid ? ge * 8u : kOob;
+        o2 = pvalid ? ge * 2u : kOob;
+        o1 = pvalid ? (unsigned)cx.fr0 * cx.P32 + p : kOob;
+    };
+    auto load_tile = [&](unsigned o8, unsigned o2, unsigned o1) {
+        const unsigned o2r = RU ? o2 : kOob;
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            xi[t] = buf_ld8(cx.rX, o1, (unsigned)(4 * t) * cx.P32);
+            if (MODE == 2) {
+                mv[t] = buf_ld64(cx.rM, o8, (unsigned)(4 * t) * ROWSTEP * 8u);
+                uf[t] = buf_ld16h(cx.rU, t == 0 ? o2 : o2r, (unsigned)(4 * t) * ROWSTEP * 2u);
+            }
+        }
+    };
+
+    int tile = cx.nsteps > 0 ? tile_of(0) : cx.ntiles;
+    offsets(tile, vo8, vo2, vo1);
+    load_tile(vo8, vo2, vo1);
+    for (int it = 0; it < cx.nsteps && tile < cx.ntiles; ++it) {
+        if (MODE == 1) {
+            // first iteration: A_0 = 0 (:273) and Y_0 = X / dual (:272), so M_1 is a function of X alone
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                const double x = (double)xi[t];
+                const double u0 = cx.inv_mu * y0_of(x);
+                const double e = shrink2(x + u0, cx.thr);                             // :282-283
+                mv[t] = (x - e) + u0;                                              // :284
+            }
+        }
+        // ---- A_k^T = B^T M_k^T on the matrix cores, two out-frame blocks at a time (two independent accumulator
+        //      chains), then Z, Y, the start of the next iteration and the stores ----
+#pragma unroll
+        for (int bq0 = 0; bq0 < NB; bq0 += 2) {
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            if (MODE != 0) {
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (bq0 + h < NB) {
+                            const double bop = cx.sB[(4 * t + cx.fr0) * BP + 16 * (bq0 + h) + cx.pl];
+                            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc[h], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (bq0 + h >= NB) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * (bq0 + h) + r;
+                    if (t >= NK) continue;
+                    // The f64 vector unit and the f64 matrix pipe do not overlap on gfx950 (tools/f64_pipe_probe.hip), so
+                    // every f64 instruction here is time taken from the MFMAs: the element-wise part is written with
+                    // the fewest of them.  With c = clamp(raw, -cx.thr, +cx.thr) the shrinkage (:283) is E = raw - c exactly
+                    // (fl(raw - cx.thr) / fl(raw + cx.thr) / 0 in the three cases, the same roundings as max(.)+min(.)), and
+                    // M_{k+1} = X - E + U (:284) = A_k + c; the stopping norm (:297, compared at a relative 1e-3 against
+                    // iterates that move by 20 % and more) is formed in float32 from the float32 copy of M_k - A_k that the
+                    // binary16 store of U needs anyway.
+                    const double x = (double)xi[t];
+                    double a_new, u;
+                    float pkf = 0.f;
+                    if (MODE == 0) {
+                        a_new = 0.0;
+                        u = cx.inv_mu2 * y0_of(x);
+                    } else {
+                        a_new = acc[h][r];                                             // :290
+                        const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}  (:293-294)
+                        u = pk * cx.ratio;                                                // Y_k / mu_k
+                        if (MODE == 1) {
+                            const float zf = (float)(pk - cx.inv_mu * y0_of(x));          // :293 with U_0 = Y_0 / mu_0
+                            if (t == 0) zz0 += zf * zf; else zz += zf * zf;
+                            if (t == 0 || WU) pkf = (float)pk;
+                        } else if (t == 0 || RU || WU) {
+                            pkf = (float)pk;
+                            if (t == 0 || RU) {
+                                const float zf = pkf - uf[t];                          // :293
+                                if (t == 0) zz0 += zf * zf; else zz += zf * zf;
+                            }
+                        }
+                    }
+                    const double raw = (x - a_new) + u;                                // :282
+                    const double c = fmin(fmax(raw, -cx.thr2), cx.thr2);
+                    const double m2 = a_new + c;                                       // :284
+                    cx.sT[(4 * t + cx.fr0) * TP + cx.pl] = m2;
+                    if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
+                        buf_st64(m2, cx.rM, vo8, (unsigned)(4 * t) * ROWSTEP * 8u);
+                        if (t == 0 || WU) buf_st16h(pkf * cx.ratio_f, cx.rU, vo2, (unsigned)(4 * t) * ROWSTEP * 2u);
+                    }
+                    if (WS) buf_st8(sparse_u8b(raw - c), cx.rS, vo1, (unsigned)(4 * t) * cx.P32);       // clip(-E) of :244-245
+                }
+            }
+        }
+        // ---- the next tile's loads go out here: xi / mv / uf are dead, the Gram phase below needs none of them ----
+        const int tile_n = it + 1 < cx.nsteps ? tile_of(it + 1) : cx.ntiles;
+        unsigned n8, n2, n1;
+        offsets(tile_n, n8, n2, n1);
+        load_tile(n8, n2, n1);
+        // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            double tr[NB];
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) tr[fb] = cx.sT[(16 * fb + cx.pl) * TP + 4 * g + cx.fr0];
+            int pair = 0;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB; ++jb) {
+                    G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ib], tr[jb], G[pair], 0, 0, 0);
+                    ++pair;
+                }
+        }
+        tile = tile_n; vo8 = n8; vo2 = n2; vo1 = n1;
+    }
+
+}
+
 // tune: bit 0 = raised priority for the wave in the odd hardware slot of its SIMD, bit 1 = that wave also starts
 // half a tile late (A/B knobs; results do not depend on them)
-template <int NK, int MODE, bool PIPE>
+template <int NK, int MODE>
 __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, int tune)
 {
     using C = MCfg<NK>;
@@ -107,6 +256,8 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
     const double dual = st.dual_norm;
+    const double ratio = mu * inv_mu2;           // U_k = Y_k / mu_k = (M_k - A_k) mu_{k-1} / mu_k
+    const float ratio_f = (float)ratio;
     const int felems = b.fpad * (int)b.pstride;                   // b.fpad == 4 NK
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(b.X + (int64_t)w * n * P), 0, n * P, 0x00020000);
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)((sel ? b.Salt : b.S) + (int64_t)w * n * P), 0, n * P, 0x00020000);
@@ -115,10 +266,6 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
 
     // Y0 = X / dual_norm (:272) for the first two passes: one Newton step on x * (1/dual), the correctly rounded quotient
     const double rdual = 1.0 / dual;
-    auto y0_of = [&](double x) {
-        const double q = x * rdual;
-        return __builtin_fma(__builtin_fma(-q, dual, x), rdual, q);
-    };
     if (MODE != 0) {
         const double *Bm = b.Bm + (int64_t)w * n * n;
         for (int i = tid; i < NPAD * NPAD; i += 256) {
@@ -134,126 +281,29 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
     d4 G[C::NPAIR];
 #pragma unroll
     for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double zz = 0.0, zz0 = 0.0;                  // sum of z^2 over frames >= 4 / frames 0..3
+    float zz = 0.f, zz0 = 0.f;                   // sum of z^2 over frames >= 4 / frames 0..3 (float32: see the element-wise part)
 
     // a block owns groups of 8 consecutive tiles = 128 pixels (every 128-byte line of the u8 planes is touched by ONE
     // workgroup), two tiles per wave back to back; the valid tiles of a wave are a prefix of its sequence
     const int ntiles = (P + 15) >> 4;
     const int nsteps = 2 * ((((ntiles + 7) >> 3) - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
-    auto tile_of = [&](int it) { return ((int)blockIdx.x + (it >> 1) * (int)gridDim.x) * 8 + wave * 2 + (it & 1); };
 
-    int xi[NK];
-    double mv[NK];
-    float uf[NK];
-    unsigned vo8, vo2, vo1;                      // per-lane byte offsets of the current tile: f64 state, f16 copy of Y/mu, u8 planes
-    auto offsets = [&](int tile, unsigned &o8, unsigned &o2, unsigned &o1) {
-        const unsigned p = (unsigned)(tile * 16 + pl);
-        const bool pvalid = tile < ntiles && p < P32;
-        // M and U are private to this kernel: [group of 128 pixels][k-step t][tile 0..7][frame 4t + 0..3][16 px]
-        const unsigned ge = ((unsigned)tile >> 3) * (unsigned)b.fpad * 128u + ((unsigned)tile & 7u) * 64u + (unsigned)fr0 * 16u + (unsigned)pl;
-        o8 = pvalid ? ge * 8u : kOob;
-        o2 = pvalid ? ge * 2u : kOob;
-        o1 = pvalid ? (unsigned)fr0 * P32 + p : kOob;
-    };
-    auto load_tile = [&](unsigned o8, unsigned o2, unsigned o1) {
-        const unsigned o2r = ru ? o2 : kOob;
-#pragma unroll
-        for (int t = 0; t < NK; ++t) {
-            xi[t] = buf_ld8(rX, o1, (unsigned)(4 * t) * P32);
-            if (MODE == 2) {
-                mv[t] = buf_ld64(rM, o8, (unsigned)(4 * t) * ROWSTEP * 8u);
-                uf[t] = buf_ld16h(rU, t == 0 ? o2 : o2r, (unsigned)(4 * t) * ROWSTEP * 2u);
-            }
-        }
-    };
-
-    int tile = nsteps > 0 ? tile_of(0) : ntiles;
-    offsets(tile, vo8, vo2, vo1);
-    load_tile(vo8, vo2, vo1);
-    for (int it = 0; it < nsteps && tile < ntiles; ++it) {
-        const unsigned vo1s = ws ? vo1 : kOob;
-        const unsigned vo2w = wu ? vo2 : kOob;
-        if (MODE == 1) {
-            // first iteration: A_0 = 0 (:273) and Y_0 = X / dual (:272), so M_1 is a function of X alone
-#pragma unroll
-            for (int t = 0; t < NK; ++t) {
-                const double x = (double)xi[t];
-                const double u0 = inv_mu * y0_of(x);
-                const double e = shrink2(x + u0, thr);                             // :282-283
-                mv[t] = (x - e) + u0;                                              // :284
-            }
-        }
-        // ---- A_k^T = B^T M_k^T on the matrix cores, two out-frame blocks at a time (two independent accumulator
-        //      chains), then Z, Y, the start of the next iteration and the stores ----
-#pragma unroll
-        for (int bq0 = 0; bq0 < NB; bq0 += 2) {
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            if (MODE != 0) {
-#pragma unroll
-                for (int t = 0; t < NK; ++t) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (bq0 + h < NB) {
-                            const double bop = sB[(4 * t + fr0) * BP + 16 * (bq0 + h) + pl];
-                            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc[h], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (bq0 + h >= NB) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 4 * (bq0 + h) + r;
-                    if (t >= NK) continue;
-                    const double x = (double)xi[t];
-                    double a_new, y;
-                    if (MODE == 0) {
-                        a_new = 0.0;
-                        y = y0_of(x);
-                    } else {
-                        a_new = acc[h][r];                                             // :290
-                        const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}
-                        const double uprev = MODE == 2 ? (double)uf[t] : inv_mu * y0_of(x);
-                        const double z = pk - uprev;                                   // :293
-                        if (t == 0) zz0 += z * z; else zz += z * z;
-                        y = mu * pk;                                                   // :294
-                    }
-                    const double u = inv_mu2 * y;
-                    const double e2 = shrink2((x - a_new) + u, thr2);
-                    const double m2 = (x - e2) + u;
-                    sT[(4 * t + fr0) * TP + pl] = m2;
-                    if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
-                        buf_st64(m2, rM, vo8, (unsigned)(4 * t) * ROWSTEP * 8u);
-                        buf_st16h((float)u, rU, t == 0 ? vo2 : vo2w, (unsigned)(4 * t) * ROWSTEP * 2u);
-                    }
-                    buf_st8(sparse_u8b(e2), rS, vo1s, (unsigned)(4 * t) * P32);
-                }
-            }
-        }
-        // ---- the next tile's loads go out here: xi / mv / uf are dead, the Gram phase below needs none of them ----
-        const int tile_n = it + 1 < nsteps ? tile_of(it + 1) : ntiles;
-        unsigned n8, n2, n1;
-        offsets(tile_n, n8, n2, n1);
-        if (PIPE) load_tile(n8, n2, n1);
-        // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands ----
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            double tr[NB];
-#pragma unroll
-            for (int fb = 0; fb < NB; ++fb) tr[fb] = sT[(16 * fb + pl) * TP + 4 * g + fr0];
-            int pair = 0;
-#pragma unroll
-            for (int ib = 0; ib < NB; ++ib)
-#pragma unroll
-                for (int jb = ib; jb < NB; ++jb) {
-                    G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ib], tr[jb], G[pair], 0, 0, 0);
-                    ++pair;
-                }
-        }
-        if (!PIPE) load_tile(n8, n2, n1);
-        tile = tile_n; vo8 = n8; vo2 = n2; vo1 = n1;
+    PassCtx cx{rX, rS, rM, rU, sB, sT, inv_mu, thr, inv_mu2, thr2, dual, rdual, ratio, ratio_f, P32, (unsigned)b.fpad,
+               pl, fr0, wave, ntiles, nsteps, (int)blockIdx.x, (int)gridDim.x};
+    // the per-window switches of this pass (sparse-image stores, all of U read / written) are wave-uniform but only
+    // known on the device: one specialised copy of the tile loop per combination, chosen once
+    const int flags = (ws ? 1 : 0) | (ru ? 2 : 0) | (wu ? 4 : 0);
+    if (MODE == 0) pass_loop<NK, 0, true, true, true>(cx, G, zz, zz0);
+    else if (MODE == 1) { if (wu) pass_loop<NK, 1, true, true, true>(cx, G, zz, zz0); else pass_loop<NK, 1, true, true, false>(cx, G, zz, zz0); }
+    else switch (flags) {
+        case 0: pass_loop<NK, 2, false, false, false>(cx, G, zz, zz0); break;
+        case 1: pass_loop<NK, 2, true, false, false>(cx, G, zz, zz0); break;
+        case 2: pass_loop<NK, 2, false, true, false>(cx, G, zz, zz0); break;
+        case 3: pass_loop<NK, 2, true, true, false>(cx, G, zz, zz0); break;
+        case 4: pass_loop<NK, 2, false, false, true>(cx, G, zz, zz0); break;
+        case 5: pass_loop<NK, 2, true, false, true>(cx, G, zz, zz0); break;
+        case 6: pass_loop<NK, 2, false, true, true>(cx, G, zz, zz0); break;
+        default: pass_loop<NK, 2, true, true, true>(cx, G, zz, zz0); break;
     }
 
     // ---- block-level, fixed-order combination of the four waves' Gram accumulators ----
@@ -283,10 +333,10 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
         if ((i >> 4) <= (j >> 4)) gp[idx] = sG[i * NPAD + j];
     }
     if (MODE != 0) {
-        zz = zz0 + ((MODE == 1 || ru) ? zz : 0.0);           // without all of U only the first four frames count
-        for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
+        double zsum = (double)zz0 + ((MODE == 1 || ru) ? (double)zz : 0.0);     // without all of U only the first four frames count
+        for (int off = 32; off; off >>= 1) zsum += __shfl_down(zsum, off);
         __syncthreads();
-        if (lane == 0) lds[NPAD * NPAD + wave] = zz;
+        if (lane == 0) lds[NPAD * NPAD + wave] = zsum;
         __syncthreads();
         if (tid == 0)
             b.zzpart[(int64_t)w * b.nblk + blockIdx.x] =
@@ -294,21 +344,22 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
     }
 }
 
-template <int NK, int MODE, bool PIPE>
+template <int NK, int MODE>
 static void launch_m_one(hipStream_t s, const IalmBuffers &b, int sel, int tune)
 {
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_ialm_pass_m<NK, MODE, PIPE>, MCfg<NK>::lds_bytes, attr_mask)) return;
-    hipLaunchKernelGGL((k_ialm_pass_m<NK, MODE, PIPE>), dim3(b.nblk, b.nwin), dim3(256), MCfg<NK>::lds_bytes, s, b, sel, tune);
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_m<NK, MODE>, MCfg<NK>::lds_bytes, attr_mask)) return;
+    hipLaunchKernelGGL((k_ialm_pass_m<NK, MODE>), dim3(b.nblk, b.nwin), dim3(256), MCfg<NK>::lds_bytes, s, b, sel, tune);
     note_launch();
 }
 
 template <int NK>
 static void launch_m_nk(hipStream_t s, const IalmBuffers &b, int mode, int sel, int tune, bool pipe)
 {
-    if (mode == 0) { if (pipe) launch_m_one<NK, 0, true>(s, b, sel, tune); else launch_m_one<NK, 0, false>(s, b, sel, tune); }
-    else if (mode == 1) { if (pipe) launch_m_one<NK, 1, true>(s, b, sel, tune); else launch_m_one<NK, 1, false>(s, b, sel, tune); }
-    else { if (pipe) launch_m_one<NK, 2, true>(s, b, sel, tune); else launch_m_one<NK, 2, false>(s, b, sel, tune); }
+    (void)pipe;
+    if (mode == 0) launch_m_one<NK, 0>(s, b, sel, tune);
+    else if (mode == 1) launch_m_one<NK, 1>(s, b, sel, tune);
+    else launch_m_one<NK, 2>(s, b, sel, tune);
 }
 
 // frames per window -> planes of M / U state per window for this kernel

@@ -155,3 +155,26 @@ def test_raw_file_reader_has_the_frame_reader_semantics(tmp_path):
         assert reader.read_errors == ref.read_errors == 1
     with pytest.raises(ValueError):
         RawFileReader(str(raw))
+
+
+@pytest.mark.gpu
+def test_library_before_torch_shares_one_hip_runtime():
+    """A process that creates a library context BEFORE importing torch must still get a working PyTorch-ROCm (one HIP
+    runtime in the process, not the system copy plus torch's bundled one), in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from swiftwatcher_amd import _lib\n"
+        "assert 'torch' not in sys.modules\n"
+        "ctx = _lib.Context(0)\n"
+        "out = ctx.thresh_tozero_u8(np.arange(32, dtype=np.uint8), 15)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'torch lost the GPU: two HIP runtimes in one process'\n"
+        "x = torch.arange(8, device='cuda').float().sum().item()\n"
+        "out2 = ctx.thresh_tozero_u8(np.arange(32, dtype=np.uint8), 15)\n"
+        "assert x == 28.0 and out[16] == 16 and (out == out2).all()\n"
+        "print('one runtime ok')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "one runtime ok" in p.stdout, p.stdout + p.stderr
