@@ -251,7 +251,10 @@ int ialm_pass_nblk(int variant, int n, int P, int nwin)
         int per_win = (256 * 2 * 3 + nwin - 1) / nwin;   // two blocks resident per CU, three rounds
         const int cap = (ntiles + 7) / 8;          // at least two tiles per wave
         if (per_win > cap) per_win = cap;
-        if (per_win > 128) per_win = 128;
+        // the Gram partial slabs (nblk x n^2 doubles per window) are summed by k_gram_reduce, four waves per 64
+        // entries: 512 slabs are 128 loads per lane.  A lone window (the unchanged CLI's call pattern) needs that
+        // many blocks to put two on every CU.
+        if (per_win > 512) per_win = 512;
         if (per_win < 1) per_win = 1;
         return per_win;
     }

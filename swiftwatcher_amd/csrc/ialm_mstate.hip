@@ -6,15 +6,21 @@
 //     6 k-steps, 12 + 12 MFMAs per 16-pixel tile and 24 rows of state instead of 8, 16 + 12 and 32;
 //     n = 49 streams 52 rows instead of 64.  Rows n .. 4 NK - 1 read X = 0 through the buffer range check, stay
 //     exactly zero in M and U, and their sparse-image stores fall outside the buffer and are dropped.
-//   * the tile loop is software-pipelined: the next tile's loads are issued after the current tile's element-wise
-//     part, where its X / M / U registers are dead, and before its Gram phase, which only needs the LDS tile and the
-//     accumulators -- the loads fly under 12..40 MFMAs instead of being waited for at the top of the next tile.
-//   * the two waves that share a SIMD run the same program on equal tiles and fall into LOCKSTEP (measured on the
-//     block-templated kernel: matrix pipe 61 % busy, waves 60 % of their time stalled on issue, matrix and vector
-//     phases of the two waves never overlapping): one of the two (odd hardware wave slot) runs at raised priority, so
-//     it keeps the matrix pipe whenever it wants it and the other fills the gaps -- their phases drift apart for good.
+//   * what bounds the pass on gfx950 is the f64 execution unit, not HBM: f64 vector instructions and f64 MFMAs do
+//     not overlap on a SIMD (tools/f64_pipe_probe.hip: a wave pair running 8 MFMAs + 64 FMAs each takes the SUM of the
+//     two alone), so per 16-pixel tile the time is 104 MFMAs x 64 cycles + (f64 vector instructions) x ~5 cycles.
+//     The element-wise part is therefore written with the fewest f64 instructions (9-13 per element instead of 22: see
+//     pass_loop), and the per-window switches of a pass (sparse-image stores, U read / written) select one of eight
+//     specialised copies of the tile loop instead of predicating stores that are computed anyway.
+//   * a wave that has the matrix pipe to itself issues MFMAs that rotate over many accumulators more slowly than
+//     MFMAs that chain on one (tools/f64_mfma_chain_probe.hip: 103 cycles each over eight accumulators, 72 on one; two
+//     waves issuing together always reach 64): the A update runs one out-frame block at a time and the Gram phase one
+//     block pair at a time.
+//   * tried and measured without effect: issuing the next tile's loads before the Gram phase (software pipelining),
+//     raised priority or a delayed start for one wave of each SIMD pair (swk_set_pass_tuning keeps the last two as
+//     A/B knobs).
 //
-// Register layout, LDS tiles, buffer addressing and arithmetic order are those of k_ialm_pass_v3 (ialm_mfma.hip).
+// Register layout, LDS tiles and buffer addressing are those of k_ialm_pass_v3 (ialm_mfma.hip).
 #include "swk_internal.h"
 
 namespace swk {
@@ -137,91 +143,84 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                 mv[t] = (x - e) + u0;                                              // :284
             }
         }
-        // ---- A_k^T = B^T M_k^T on the matrix cores, two out-frame blocks at a time (two independent accumulator
-        //      chains), then Z, Y, the start of the next iteration and the stores ----
+        // ---- A_k^T = B^T M_k^T on the matrix cores, ONE out-frame block at a time: a wave that has the matrix pipe to
+        //      itself issues back-to-back MFMAs on one accumulator every 72 cycles, on two alternating ones every 76, on
+        //      eight every 103 (tools/f64_mfma_chain_probe.hip; two waves issuing together always reach the pipe's 64) --
+        //      then Z, Y, the start of the next iteration and the stores of that block's four frame rows ----
 #pragma unroll
-        for (int bq0 = 0; bq0 < NB; bq0 += 2) {
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+        for (int bq = 0; bq < NB; ++bq) {
+            d4 acc1 = d4{0.0, 0.0, 0.0, 0.0};
             if (MODE != 0) {
 #pragma unroll
                 for (int t = 0; t < NK; ++t) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (bq0 + h < NB) {
-                            const double bop = cx.sB[(4 * t + cx.fr0) * BP + 16 * (bq0 + h) + cx.pl];
-                            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc[h], 0, 0, 0);
-                        }
-                    }
+                    const double bop = cx.sB[(4 * t + cx.fr0) * BP + 16 * bq + cx.pl];
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, mv[t], acc1, 0, 0, 0);
                 }
             }
+            // The f64 vector unit and the f64 matrix pipe do not overlap on gfx950 (tools/f64_pipe_probe.hip), so every
+            // f64 instruction here is time taken from the MFMAs: the element-wise part is written with the fewest of them.
+            // With c = clamp(raw, -thr, +thr) the shrinkage (:283) is E = raw - c exactly (fl(raw - thr) / fl(raw + thr) / 0
+            // in the three cases, the same roundings as max(.) + min(.)), and M_{k+1} = X - E + U (:284) = A_k + c; the
+            // stopping norm (:297, compared at a relative 1e-3 against iterates that move by 20 % and more) is formed in
+            // float32 from the float32 copy of M_k - A_k that the binary16 store of U needs anyway.
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (bq0 + h >= NB) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 4 * (bq0 + h) + r;
-                    if (t >= NK) continue;
-                    // The f64 vector unit and the f64 matrix pipe do not overlap on gfx950 (tools/f64_pipe_probe.hip), so
-                    // every f64 instruction here is time taken from the MFMAs: the element-wise part is written with
-                    // the fewest of them.  With c = clamp(raw, -cx.thr, +cx.thr) the shrinkage (:283) is E = raw - c exactly
-                    // (fl(raw - cx.thr) / fl(raw + cx.thr) / 0 in the three cases, the same roundings as max(.)+min(.)), and
-                    // M_{k+1} = X - E + U (:284) = A_k + c; the stopping norm (:297, compared at a relative 1e-3 against
-                    // iterates that move by 20 % and more) is formed in float32 from the float32 copy of M_k - A_k that the
-                    // binary16 store of U needs anyway.
-                    const double x = (double)xi[t];
-                    double a_new, u;
-                    float pkf = 0.f;
-                    if (MODE == 0) {
-                        a_new = 0.0;
-                        u = cx.inv_mu2 * y0_of(x);
-                    } else {
-                        a_new = acc[h][r];                                             // :290
-                        const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}  (:293-294)
-                        u = pk * cx.ratio;                                                // Y_k / mu_k
-                        if (MODE == 1) {
-                            const float zf = (float)(pk - cx.inv_mu * y0_of(x));          // :293 with U_0 = Y_0 / mu_0
+            for (int r = 0; r < 4; ++r) {
+                const int t = 4 * bq + r;
+                if (t >= NK) continue;
+                const double x = (double)xi[t];
+                double a_new, raw;
+                float pkf = 0.f;
+                if (MODE == 0) {
+                    a_new = 0.0;
+                    raw = x + cx.inv_mu2 * y0_of(x);                               // :282 with A_0 = 0, Y_0 = X / dual
+                } else {
+                    a_new = acc1[r];                                               // :290
+                    const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}  (:293-294)
+                    raw = __builtin_fma(pk, cx.ratio, x - a_new);                  // :282, (X - A_k) + Y_k / mu_k
+                    if (MODE == 1) {
+                        const float zf = (float)(pk - cx.inv_mu * y0_of(x));       // :293 with U_0 = Y_0 / mu_0
+                        if (t == 0) zz0 += zf * zf; else zz += zf * zf;
+                        if (t == 0 || WU) pkf = (float)pk;
+                    } else if (t == 0 || RU || WU) {
+                        pkf = (float)pk;
+                        if (t == 0 || RU) {
+                            const float zf = pkf - uf[t];                          // :293
                             if (t == 0) zz0 += zf * zf; else zz += zf * zf;
-                            if (t == 0 || WU) pkf = (float)pk;
-                        } else if (t == 0 || RU || WU) {
-                            pkf = (float)pk;
-                            if (t == 0 || RU) {
-                                const float zf = pkf - uf[t];                          // :293
-                                if (t == 0) zz0 += zf * zf; else zz += zf * zf;
-                            }
                         }
                     }
-                    const double raw = (x - a_new) + u;                                // :282
-                    const double c = fmin(fmax(raw, -cx.thr2), cx.thr2);
-                    const double m2 = a_new + c;                                       // :284
-                    cx.sT[(4 * t + cx.fr0) * TP + cx.pl] = m2;
-                    if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
-                        buf_st64(m2, cx.rM, vo8, (unsigned)(4 * t) * ROWSTEP * 8u);
-                        if (t == 0 || WU) buf_st16h(pkf * cx.ratio_f, cx.rU, vo2, (unsigned)(4 * t) * ROWSTEP * 2u);
-                    }
-                    if (WS) buf_st8(sparse_u8b(raw - c), cx.rS, vo1, (unsigned)(4 * t) * cx.P32);       // clip(-E) of :244-245
                 }
+                const double c = fmin(fmax(raw, -cx.thr2), cx.thr2);
+                const double m2 = a_new + c;                                       // :284
+                cx.sT[(4 * t + cx.fr0) * TP + cx.pl] = m2;
+                if (MODE != 0) {         // the start pass leaves no state: pass 1 rebuilds M_1 from X
+                    buf_st64(m2, cx.rM, vo8, (unsigned)(4 * t) * ROWSTEP * 8u);
+                    if (t == 0 || WU) buf_st16h(pkf * cx.ratio_f, cx.rU, vo2, (unsigned)(4 * t) * ROWSTEP * 2u);
+                }
+                if (WS) buf_st8(sparse_u8b(raw - c), cx.rS, vo1, (unsigned)(4 * t) * cx.P32);   // clip(-E) of :244-245
             }
         }
-        // ---- the next tile's loads go out here: xi / mv / uf are dead, the Gram phase below needs none of them ----
-        const int tile_n = it + 1 < cx.nsteps ? tile_of(it + 1) : cx.ntiles;
-        unsigned n8, n2, n1;
-        offsets(tile_n, n8, n2, n1);
-        load_tile(n8, n2, n1);
-        // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands ----
+        // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands; one block pair at a time, its four
+        //      MFMAs (16 pixels = 4 k-steps) back to back on the pair's accumulator ----
+        {
+            double tr[4][NB];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            double tr[NB];
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int fb = 0; fb < NB; ++fb) tr[fb] = cx.sT[(16 * fb + cx.pl) * TP + 4 * g + cx.fr0];
+                for (int fb = 0; fb < NB; ++fb) tr[g][fb] = cx.sT[(16 * fb + cx.pl) * TP + 4 * g + cx.fr0];
             int pair = 0;
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
                 for (int jb = ib; jb < NB; ++jb) {
-                    G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[ib], tr[jb], G[pair], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) G[pair] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[g][ib], tr[g][jb], G[pair], 0, 0, 0);
                     ++pair;
                 }
         }
+        const int tile_n = it + 1 < cx.nsteps ? tile_of(it + 1) : cx.ntiles;
+        unsigned n8, n2, n1;
+        offsets(tile_n, n8, n2, n1);
+        load_tile(n8, n2, n1);
         tile = tile_n; vo8 = n8; vo2 = n2; vo1 = n1;
     }
 

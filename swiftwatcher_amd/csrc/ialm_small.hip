@@ -35,7 +35,7 @@ __device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, in
 __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int k, double lmbda, double tol, int maxiter,
                                                double *red, IalmScal &cur)
 {
-    const int tid = threadIdx.x, nblk = b.nblk;
+    const int tid = threadIdx.x, nblk = b.nblk, nthreads = blockDim.x;
     IalmWin &st = b.win[w];
     if (st.done) return false;
     // every thread takes its copy of the window state BEFORE the reduction's barriers: thread 0 rewrites ru / wu
@@ -44,10 +44,10 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
     const double dnorm = st.dnorm;
     if (k >= 1) {
         double acc = 0.0;
-        for (int i = tid; i < nblk; i += kSmallThreads) acc += b.zzpart[(int64_t)w * nblk + i];
+        for (int i = tid; i < nblk; i += nthreads) acc += b.zzpart[(int64_t)w * nblk + i];
         red[tid] = acc;
         __syncthreads();
-        for (int s = kSmallThreads / 2; s; s >>= 1) {
+        for (int s = nthreads / 2; s; s >>= 1) {
             if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
@@ -106,14 +106,14 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
 // The MFMA pass only fills frame-block pairs ib <= jb (G is symmetric): the rest is mirrored.
 __device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double *G, int pitch, int k)
 {
-    const int n = b.n, nblk = b.nblk, nred = b.nred;
+    const int n = b.n, nblk = b.nblk, nred = b.nred, nthreads = blockDim.x;
     // first iteration from the integer kernel: the slabs hold X^T X and M_1 = (1 + 1/(mu_0 dual)) X (ialm_gram8.hip);
     // st.cur is mu_0 at this point (small_prologue has run)
     const IalmWin &st = b.win[w];
     double scale = 1.0;
     if (k == 0 && st.int_gram) { const double s1 = 1.0 + st.cur.inv_mu / st.dual_norm; scale = s1 * s1; }
     const double *gp = b.gpart + (int64_t)w * nblk * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += kSmallThreads) {
+    for (int idx = threadIdx.x; idx < n * n; idx += nthreads) {
         const int i = idx / n, j = idx - i * n;
         const int src = (i >> 4) <= (j >> 4) ? idx : j * n + i;
         double acc = 0.0;
@@ -129,8 +129,8 @@ __device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double 
 // ---------------------------------------------------------------------------------
 __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double2 *cs, int *pq, double *wgt, int *flag, int *sweeps_out)
 {
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < n * n; idx += kSmallThreads) { const int i = idx / n, j = idx - i * n; V[i * kJac + j] = i == j ? 1.0 : 0.0; }
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int idx = tid; idx < n * n; idx += nthreads) { const int i = idx / n, j = idx - i * n; V[i * kJac + j] = i == j ? 1.0 : 0.0; }
     if ((n & 1) && tid <= n) {                 // zero row/column at the dummy index of an odd n
         G[n * kJac + tid] = 0.0;
         G[tid * kJac + n] = 0.0;
@@ -162,7 +162,7 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
                 pq[tid] = p | (q << 8);
             }
             __syncthreads();
-            for (int idx = tid; idx < half * half; idx += kSmallThreads) {
+            for (int idx = tid; idx < half * half; idx += nthreads) {
                 const int ka = idx / half, kb = idx - ka * half;
                 const double2 ra = cs[ka], rb = cs[kb];
                 if (ra.y == 0.0 && rb.y == 0.0) continue;
@@ -177,7 +177,7 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
                 G[qa * kJac + pb] = rb.x * r10 - rb.y * r11;
                 G[qa * kJac + qb] = rb.y * r10 + rb.x * r11;
             }
-            for (int idx = tid; idx < n * half; idx += kSmallThreads) {
+            for (int idx = tid; idx < n * half; idx += nthreads) {
                 const int i = idx / half, kk = idx - i * half;
                 const double2 rk = cs[kk];
                 if (rk.y == 0.0) continue;
@@ -203,7 +203,7 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
         if (tid < n) wgt[tid] = lam > 1e-13 * lmax ? 1.0 / sqrt(lam) : 0.0;
     }
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+    for (int idx = tid; idx < n * n; idx += nthreads) {
         const int i = idx / n, j = idx - i * n;
         double acc = 0.0;
         for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
     double2 *cs = (double2 *)(red + kSmallThreads);                           // [32]
     double *wgt = red + kSmallThreads + 64;                                   // [64]
     int *ints = (int *)(wgt + kMaxN);                                         // pq[32], flag, sweeps, dead mask...
-    const int w = blockIdx.x, tid = threadIdx.x, n = b.n;
+    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nthreads = blockDim.x;      // 256 threads for n <= 32, else 1024
     const int lane = tid & 63, wave = tid >> 6;
     IalmScal cur;
     if (!small_prologue(b, w, k, lmbda, tol, maxiter, red, cur)) return;
@@ -278,16 +278,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
     int ns_iters = 0;
     if (!need_jacobi) {
         // ---- Y = G (padded with zeros), Z = I ----
-        for (int idx = tid; idx < NPAD * PITCH; idx += kSmallThreads) { Y[idx] = 0.0; Z[idx] = 0.0; }
+        for (int idx = tid; idx < NPAD * PITCH; idx += nthreads) { Y[idx] = 0.0; Z[idx] = 0.0; }
         __syncthreads();
         gram_reduce(b, w, Y, PITCH, k);
         __syncthreads();
         // s = ||G||_F (fixed-order reduction)
         double acc = 0.0;
-        for (int idx = tid; idx < n * n; idx += kSmallThreads) { const double v = Y[(idx / n) * PITCH + idx % n]; acc += v * v; }
+        for (int idx = tid; idx < n * n; idx += nthreads) { const double v = Y[(idx / n) * PITCH + idx % n]; acc += v * v; }
         red[tid] = acc;
         __syncthreads();
-        for (int s = kSmallThreads / 2; s; s >>= 1) {
+        for (int s = nthreads / 2; s; s >>= 1) {
             if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         __syncthreads();
         if (tid < NPAD) ints[40 + tid] = (tid >= n || Y[tid * PITCH + tid] == 0.0) ? 1 : 0;      // dead directions
         __syncthreads();
-        for (int idx = tid; idx < NPAD * NPAD; idx += kSmallThreads) {
+        for (int idx = tid; idx < NPAD * NPAD; idx += nthreads) {
             const int i = idx / NPAD, j = idx - i * NPAD;
             const bool dead = ints[40 + i] || ints[40 + j];
             Y[i * PITCH + j] = dead ? (i == j ? 1.0 : 0.0) : Y[i * PITCH + j] * inv_sc;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             lo = lo < 0.9999 ? lo * (ta - tc * lo * lo) : 1.0;
             // phase 1: P = Z Y;  T = ta I - tc P  (= (3I - P)/2 once alpha = 1);  residual ||I - P||_F^2
             double r2 = 0.0;
-            for (int t = wave; t < NT; t += kSmallThreads / 64) {
+            for (int t = wave; t < NT; t += nthreads / 64) {
                 const int ti = t / NB, tj = t - ti * NB;
                 d4 p = mm_tile<NPAD, PITCH>(Z, Y, ti, tj, lane);
                 d4 tt;
@@ -339,10 +339,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             if (lane == 0) red[wave] = r2;
             __syncthreads();
             double res2 = 0.0;
-            for (int i = 0; i < kSmallThreads / 64; ++i) res2 += red[i];
+            for (int i = 0; i < nthreads / 64; ++i) res2 += red[i];
             // phase 2: Y T and T Z into registers (both read the old Y, Z), then write back
             d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
-            const int j0 = wave, j1 = wave + kSmallThreads / 64;
+            const int j0 = wave, j1 = wave + nthreads / 64;
             const int t0 = j0 % NT, t1 = j1 % NT;
             const int ti0 = t0 / NB, tj0 = t0 - ti0 * NB, ti1 = t1 / NB, tj1 = t1 - ti1 * NB;
             if (j0 < 2 * NT) o0 = j0 < NT ? mm_tile<NPAD, PITCH>(Y, T, ti0, tj0, lane) : mm_tile<NPAD, PITCH>(T, Z, ti0, tj0, lane);
@@ -364,11 +364,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             // Jacobi solver, which gives eigenvalues below 1e-13 lambda_max the weight 0 (the project's defined
             // behaviour for zero singular directions).
             double zacc = 0.0;
-            for (int idx = tid; idx < n * n; idx += kSmallThreads) { const double v = Z[(idx / n) * PITCH + idx % n]; zacc += v * v; }
+            for (int idx = tid; idx < n * n; idx += nthreads) { const double v = Z[(idx / n) * PITCH + idx % n]; zacc += v * v; }
             __syncthreads();
             red[tid] = zacc;
             __syncthreads();
-            for (int s = kSmallThreads / 2; s; s >>= 1) {
+            for (int s = nthreads / 2; s; s >>= 1) {
                 if (tid < s) red[tid] += red[tid + s];
                 __syncthreads();
             }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         }
         if (converged) {
             const double wscale = 1.0 / sqrt(sc);
-            for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+            for (int idx = tid; idx < n * n; idx += nthreads) {
                 const int i = idx / n, j = idx - i * n;
                 const bool dead = ints[40 + i] || ints[40 + j];
                 const double wv = dead ? 0.0 : 0.5 * (Z[i * PITCH + j] + Z[j * PITCH + i]) * wscale;
@@ -395,31 +395,38 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
     __syncthreads();
     int sweeps = 0;
     jacobi_invsqrt(G, V, Wm, n, cs, ints, wgt, ints + 36, &sweeps);
-    for (int idx = tid; idx < n * n; idx += kSmallThreads) {
+    for (int idx = tid; idx < n * n; idx += nthreads) {
         const int i = idx / n, j = idx - i * n;
         Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * Wm[i * kJac + j];
     }
     if (tid == 0) st.sweeps = 100 + sweeps;
 }
 
-// With many slabs per window (small batches use many blocks per window) the sum is done by the whole chip
-// first: one thread per matrix entry, slabs added in index order -> same result as the in-kernel loop.
+// With many slabs per window (small batches use many blocks per window) the sum is done by the whole chip first:
+// a block takes 64 matrix entries (lane = entry: coalesced), each of its four waves a quarter of the slabs, and the four
+// partial sums are combined in wave order -- a fixed summation order, so results are reproducible.
 __global__ __launch_bounds__(256) void k_gram_reduce(IalmBuffers b)
 {
     const int w = blockIdx.y, n = b.n;
     if (b.win[w].done) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
+    // the passes only write frame-block pairs ib <= jb
+    const bool live = idx < n * n && ((idx / n) >> 4) <= ((idx % n) >> 4);
     double *gp = b.gpart + (int64_t)w * b.nblk * n * n;
-    if (((idx / n) >> 4) > ((idx % n) >> 4)) return;       // the passes only write frame-block pairs ib <= jb
+    const int per = (b.nblk + 3) / 4, b0 = wave * per, b1 = min(b0 + per, b.nblk);
     double acc = 0.0;
-    for (int bk = 0; bk < b.nblk; ++bk) acc += gp[(int64_t)bk * n * n + idx];
-    gp[idx] = acc;
+    if (live)
+        for (int bk = b0; bk < b1; ++bk) acc += gp[(int64_t)bk * n * n + idx];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) gp[idx] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
 {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 255) / 256, b.nwin), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 63) / 64, b.nwin), dim3(256), 0, s, b);
 }
 
 template <int NB>
@@ -427,7 +434,8 @@ static void launch_small_nb(hipStream_t s, const IalmBuffers &b, int k, double l
 {
     static unsigned long long attr_mask = 0;
     if (!ensure_dyn_lds((const void *)k_ialm_small<NB>, NsCfg<NB>::lds_bytes, attr_mask)) return;
-    hipLaunchKernelGGL((k_ialm_small<NB>), dim3(b.nwin), dim3(kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda, tol, maxiter, method);
+    // up to 32 frames the matrices are 2 x 2 tiles: four waves do them without idling twelve more at every barrier
+    hipLaunchKernelGGL((k_ialm_small<NB>), dim3(b.nwin), dim3(NB <= 2 ? 256 : kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda, tol, maxiter, method);
     note_launch();
 }
 

@@ -353,12 +353,17 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
         // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
         { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0, ctx->pass_tune); }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->gstream[g], ctx->ev_pass[g], 0));
-        { Timed t(ctx, SWK_K_IALM_SMALL, ctx->gstream[g]);
-          if (grp[g].b.nblk > 4) launch_gram_reduce(ctx->gstream[g], grp[g].b);
-          launch_ialm_small(ctx->gstream[g], grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], ctx->gstream[g]));
+        // one group: everything in order on the main stream (no cross-stream events: a lone window's iteration is a
+        // chain of three short kernels, and every event hop costs microseconds of it)
+        hipStream_t gs0 = ngroups == 1 ? s : ctx->gstream[g];
+        if (ngroups > 1) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
+            HIPCHK(ctx, hipStreamWaitEvent(gs0, ctx->ev_pass[g], 0));
+        }
+        { Timed t(ctx, SWK_K_IALM_SMALL, gs0);
+          if (grp[g].b.nblk > 4) launch_gram_reduce(gs0, grp[g].b);
+          launch_ialm_small(gs0, grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
+        if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs0));
     }
     for (int k = 1; k <= maxiter + 2; ++k) {
         bool any = false;
@@ -374,15 +379,17 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             }
             if (k > maxiter) { gr.finished = true; continue; }
             any = true;
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
+            if (ngroups > 1) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
             { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant, k, ctx->pass_tune); }
-            HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
-            hipStream_t gs = ctx->gstream[g];
-            HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
+            hipStream_t gs = ngroups == 1 ? s : ctx->gstream[g];
+            if (ngroups > 1) {
+                HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
+                HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
+            }
             { Timed t(ctx, SWK_K_IALM_SMALL, gs);
               if (gr.b.nblk > 4) launch_gram_reduce(gs, gr.b);
               launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
-            HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
+            if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
             if (k >= check_from) {
                 HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));
                 HIPCHK(ctx, hipEventRecord(ctx->ev_poll[g][k & 1], gs));
@@ -391,7 +398,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         if (!any) break;
     }
     // everything after the IALM runs on the main stream: join the side streams
-    for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
+    if (ngroups > 1) for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
     if (mstate) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
     if (mstate && (b.spec > 0.0 || b.nspec > 0.0)) {
         // did any window stop right after a pass that had its sparse-image stores switched off?
