@@ -252,7 +252,7 @@ int32_t swk_prof_reset(swk_ctx *ctx);
 int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *launches);
 /* Total IALM pass launches x windows still active, i.e. window-iterations streamed. */
 int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
-/* Select the IALM pass kernel: 0 = auto (3, or 2 when A / E are requested), 1 = LDS/VALU kernel,
+/* Select the IALM pass kernel: 0 = auto (4, or 2 when A / E are requested), 1 = LDS/VALU kernel,
  * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per
  * element and iteration; produces the sparse u8 image and the iteration count, not A / E), instantiated per 16-frame
  * block; 4 = the same pass instantiated per 4-frame k-step with a software-pipelined tile loop, 5 = 4 without the pipeline.
@@ -278,6 +278,9 @@ int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
 int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on);
 /* Windows of the last swk_batch_run / swk_ialm whose start came from the integer kernel (the others ran the f64 start pass). */
 int32_t swk_last_integer_start_windows(swk_ctx *ctx, int32_t *windows);
+/* Diagnostic: iterations the G^(-1/2) solver took in the LAST small-matrix step of the last batch, maximum over its
+ * windows: Newton-Schulz iterations, or 100 + Jacobi sweeps where that solver ran. */
+int32_t swk_last_eig_sweeps(swk_ctx *ctx, int32_t *sweeps);
 int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
 /* M-state pass: algorithmic bytes per matrix element moved by all its launches since swk_prof_reset, summed over
  * windows (each window-iteration counts X 1 + M 8 (+8 read) + U 2 or 1/8 each way + 1 when the sparse image is

@@ -83,6 +83,7 @@ _SIGS = {
     "swk_set_sparse_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_set_integer_start": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_last_integer_start_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_last_eig_sweeps": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -259,6 +260,12 @@ class Context:
     def pass_bytes_per_element(self):
         v = ctypes.c_double(0)
         self._check(self._lib.swk_prof_pass_bytes_per_element(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def last_eig_sweeps(self):
+        v = ctypes.c_int32(0)
+        self._check(self._lib.swk_last_eig_sweeps(self._h, ctypes.byref(v)))
         return v.value
 
     @property

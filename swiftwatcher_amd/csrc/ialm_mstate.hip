@@ -16,9 +16,10 @@
 //     MFMAs that chain on one (tools/f64_mfma_chain_probe.hip: 103 cycles each over eight accumulators, 72 on one; two
 //     waves issuing together always reach 64): the A update runs one out-frame block at a time and the Gram phase one
 //     block pair at a time.
-//   * tried and measured without effect: issuing the next tile's loads before the Gram phase (software pipelining),
-//     raised priority or a delayed start for one wave of each SIMD pair (swk_set_pass_tuning keeps the last two as
-//     A/B knobs).
+//   * up to 32 frames the tile loop is software-pipelined (the next tile's loads are issued before the Gram phase);
+//     with more frames that makes no difference (measured) and the registers go to the Gram operands.
+//   * tried and measured without effect: raised priority or a delayed start for one wave of each SIMD pair
+//     (swk_set_pass_tuning keeps them as A/B knobs).
 //
 // Register layout, LDS tiles and buffer addressing are those of k_ialm_pass_v3 (ialm_mfma.hip).
 #include "swk_internal.h"
@@ -99,6 +100,7 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
 {
     using C = MCfg<NK>;
     constexpr int NB = C::NB, BP = C::BP, TP = C::TP;
+    constexpr bool PIPE = NB <= 2;
     auto y0_of = [&](double x) {
         const double q = x * cx.rdual;
         return __builtin_fma(__builtin_fma(-q, cx.dual, x), cx.rdual, q);
@@ -199,6 +201,13 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                 if (WS) buf_st8(sparse_u8b(raw - c), cx.rS, vo1, (unsigned)(4 * t) * cx.P32);   // clip(-E) of :244-245
             }
         }
+        // ---- up to 32 frames (registers to spare, four waves per SIMD, fewer flops per byte) the next tile's loads go out
+        //      here, where xi / mv / uf are dead, and fly under the Gram phase: 3.1 instead of 3.5 ms per launch at
+        //      n = 21.  With more frames the registers hold the Gram operands instead and the loads follow it ----
+        const int tile_n = it + 1 < cx.nsteps ? tile_of(it + 1) : cx.ntiles;
+        unsigned n8, n2, n1;
+        offsets(tile_n, n8, n2, n1);
+        if (PIPE) load_tile(n8, n2, n1);
         // ---- Gram of M_{k+1}: the transposed registers are both MFMA operands; one block pair at a time, its four
         //      MFMAs (16 pixels = 4 k-steps) back to back on the pair's accumulator ----
         {
@@ -217,10 +226,7 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                     ++pair;
                 }
         }
-        const int tile_n = it + 1 < cx.nsteps ? tile_of(it + 1) : cx.ntiles;
-        unsigned n8, n2, n1;
-        offsets(tile_n, n8, n2, n1);
-        load_tile(n8, n2, n1);
+        if (!PIPE) load_tile(n8, n2, n1);
         tile = tile_n; vo8 = n8; vo2 = n2; vo1 = n1;
     }
 

@@ -49,6 +49,7 @@ struct swk_ctx {
     int pass_tune = 0;             // k-step-templated pass: bit 0 priority, bit 1 stagger for the odd hardware wave slot
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     int64_t redo_batches = 0;
+    int last_eig_sweeps = 0;       // largest IalmWin::sweeps of the last batch (Newton-Schulz iterations, or 100 + Jacobi sweeps)
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
@@ -253,10 +254,10 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
-    // auto: the M-state pass (v3, 21 B/element) unless the caller wants the f64 low-rank / sparse matrices,
+    // auto: the M-state pass (k-step-templated, 21 B/element) unless the caller wants the f64 low-rank / sparse matrices,
     // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = ctx->ialm_variant;
-    if (variant == 0) variant = 3;
+    if (variant == 0) variant = 4;
     if (variant >= 3 && (want_A || want_E)) variant = 2;
     const bool mstate = variant >= 3;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
     // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
@@ -429,9 +430,11 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     HIPCHK(ctx, hipMemcpy(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost));
     std::vector<int32_t> it(nwin);
     ctx->last_int_start = 0;
+    ctx->last_eig_sweeps = 0;
     for (int w = 0; w < nwin; ++w) {
         it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; ctx->pass_b16 += hw[w].pass_b16;
         ctx->last_int_start += hw[w].int_gram ? 1 : 0;
+        if (hw[w].sweeps > ctx->last_eig_sweeps) ctx->last_eig_sweeps = hw[w].sweeps;
     }
     if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
     if (d_iters) HIPCHK(ctx, hipMemcpy(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice));
@@ -595,6 +598,12 @@ int32_t swk_prof_pass_bytes_per_element(swk_ctx *ctx, double *bytes)
 {
     if (!ctx || !bytes) return SWK_ERR_ARG;
     *bytes = (double)ctx->pass_b16 / 16.0;
+    return SWK_OK;
+}
+int32_t swk_last_eig_sweeps(swk_ctx *ctx, int32_t *sweeps)
+{
+    if (!ctx || !sweeps) return SWK_ERR_ARG;
+    *sweeps = ctx->last_eig_sweeps;
     return SWK_OK;
 }
 int32_t swk_last_integer_start_windows(swk_ctx *ctx, int32_t *windows)

@@ -310,9 +310,13 @@ def test_mstate_pass_every_kstep_count(orc):
     priority / stagger knobs -- all bit-identical to the block-templated kernel (itself checked against the oracle
     throughout this file), and to the oracle directly for the CLI's queue of 21 and for n = 49."""
     from swiftwatcher_amd import _lib, synthetic
-    cases = [(1, 120, 200), (3, 90, 130), (4, 90, 130), (5, 80, 120), (9, 64, 100), (13, 64, 90), (18, 50, 90), (21, 61, 93),
-             (26, 48, 80), (31, 48, 70), (36, 48, 70), (37, 48, 66), (45, 40, 70), (49, 40, 66), (52, 40, 60), (57, 40, 60),
-             (61, 36, 60), (64, 36, 58)]
+    # every window holds >= 1.4e5 elements: below about 1.1e5 the first shrinkage clips most of the sky, iteration 1 sees a
+    # rank-deficient M and the trajectory is chaotic in the last bit of the arithmetic (the reference itself is
+    # LAPACK-dependent there, DESIGN.md section 2) -- no two correct kernels have to agree on such a window
+    cases = []
+    for n in (1, 3, 4, 5, 9, 13, 18, 21, 26, 31, 36, 37, 45, 49, 52, 57, 61, 64):
+        Wc = 61 + 2 * (n % 7) + (140000 // n) // 300
+        cases.append((n, -(-140000 // (n * Wc)) + 1, Wc))
     ctxs = {}
     for key, (variant, tune) in {"block": (3, 0), "pipe": (4, 0), "pipe+prio": (4, 1), "pipe+prio+stagger": (4, 3),
                                  "plain": (5, 0), "plain+prio": (5, 1)}.items():

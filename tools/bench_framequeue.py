@@ -41,5 +41,5 @@ for n, keep in [(21, True), (21, False), (64, True), (64, False)]:
     while not q.is_empty():
         q.pop_frame()
     out["n%d_keep%d" % (n, keep)] = {"ms_per_window": round(t * 1e3, 2), "frames_per_s": round(n / t, 1), "segments": nseg,
-                                    "iters": q.last_iters, "device_ms_by_family": fam}
+                                    "iters": q.last_iters, "device_ms_by_family": fam, "eig_sweeps_last": ctx.last_eig_sweeps}
 print(json.dumps(out))
