@@ -61,6 +61,16 @@ int32_t swk_track_costs(const double *prev_c, const double *prev_hist0, const ui
 // tie rule (among equal shortest-path costs prefer an unassigned column; columns are scanned from the
 // `remaining` list that starts as n_cols-1 .. 0), so equal-cost ties resolve as in SciPy.
 // cost is row-major n_rows x n_cols with n_rows <= n_cols; col4row[i] receives the column of row i.
+//
+// Which SciPy: the reference pins scipy==1.3.1 (requirements.txt:15), whose linear_sum_assignment is the older Munkres
+// implementation; parity here is defined against SciPy >= 1.4 (fixtures recorded under 1.7.1, cross-checked with 1.15.3).
+// The two can differ only in which of several equal-cost permutations they return, and
+// tests/test_tracking_counts.py::test_ties_among_structural_cells_cannot_change_statuses shows by brute force that every
+// optimal assignment of this cost structure yields the same matches and D / A statuses.
+//
+// This function follows scipy/optimize/rectangular_lsap/rectangular_lsap.cpp closely (variable names included, so the
+// two can be compared line by line).  That file is Copyright (c) 2019 PM Larsen and the SciPy developers, distributed
+// under the 3-clause BSD licence; the notice is reproduced in THIRD_PARTY_NOTICES.md at the repository root.
 int32_t swk_lsap(const double *cost, int32_t n_rows, int32_t n_cols, int32_t *col4row)
 {
     if (!cost || !col4row || n_rows < 0 || n_cols < n_rows) return SWK_ERR_ARG;
