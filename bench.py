@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--no-classify", action="store_true",
                     help="time the image_filtering part only (the headline metric then reads 'segment'); for kernel A/Bs")
     ap.add_argument("--full-network", action="store_true", help="A/B: the full 224x224 forward instead of the receptive-field cropped one")
-    ap.add_argument("--cls-batch", type=int, default=2048, help="segments per classifier forward")
+    ap.add_argument("--cls-batch", type=int, default=4096, help="segments per classifier forward")
+    ap.add_argument("--cudnn-benchmark", action="store_true", help="A/B: torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--tune", type=int, default=None, help="A/B: swk_set_pass_tuning flags (variants 4 / 5)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
@@ -147,6 +148,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     classify = not args.no_classify
+    if args.cudnn_benchmark:
+        torch.backends.cudnn.benchmark = True
 
     geo = getattr(synthetic, args.size)
     Hc, Wc, n, nwin = geo["Hc"], geo["Wc"], args.n, args.windows

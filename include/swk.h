@@ -132,6 +132,11 @@ const char *swk_last_error(const swk_ctx *ctx);   /* ctx may be NULL: last creat
 /* Bytes of device memory the context holds (for sizing against 288 GB HBM). */
 int64_t swk_ctx_device_bytes(const swk_ctx *ctx);
 
+/* Page-locked host memory for staging buffers the caller fills and then passes as swk_input.frames (SWK_MEM_HOST): the
+ * copy to the device is then a single DMA.  No context needed; free with swk_pinned_free. */
+int32_t swk_pinned_alloc(int64_t bytes, void **out);
+int32_t swk_pinned_free(void *p);
+
 /* ---- the hot path --------------------------------------------------------------
  * Replaces, for a batch of windows, FrameQueue.preprocess_queue + segment_queue
  * (data_structures.py:171-217): crop -> gray -> RPCA/IALM -> bilateral -> to-zero

@@ -98,6 +98,8 @@ _SIGS = {
     "swk_canny_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_dilate_up_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_roi_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "swk_pinned_alloc": (ctypes.c_int32, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "swk_pinned_free": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
@@ -467,6 +469,22 @@ def lsap(cost):
     if rc:
         raise SwkError("swk_lsap failed (%d)" % rc)
     return out
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (swk_pinned_alloc): staging buffer for host -> device input, freed when the
+    array (and every view of it) is gone.  Falls back to ordinary memory when pinning fails: pinning is an
+    optimisation, never a requirement."""
+    import weakref
+    count = int(np.prod(shape))
+    nbytes = max(count * np.dtype(dtype).itemsize, 1)
+    lib = load()
+    ptr = ctypes.c_void_p()
+    if lib.swk_pinned_alloc(nbytes, ctypes.byref(ptr)) != 0 or not ptr.value:
+        return np.empty(shape, dtype)
+    buf = (ctypes.c_uint8 * nbytes).from_address(ptr.value)      # numpy keeps this object alive as .base
+    weakref.finalize(buf, lib.swk_pinned_free, ctypes.c_void_p(ptr.value))
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 # ---- ROI mask of a video (host side, no GPU): image_filtering.py:99-180 ----

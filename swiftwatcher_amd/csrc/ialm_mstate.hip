@@ -60,10 +60,11 @@ __device__ __forceinline__ void buf_st8(int v, __amdgpu_buffer_rsrc_t r, unsigne
 {
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff, soff, 0);
 }
+// returns U / 128 as stored: the stopping norm is accumulated in that scale and multiplied by 128^2 once at the end
 __device__ __forceinline__ float buf_ld16h(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     const unsigned short bits = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
-    return (float)__builtin_bit_cast(_Float16, bits) * kUUnscale;
+    return (float)__builtin_bit_cast(_Float16, bits);
 }
 __device__ __forceinline__ void buf_st16h(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
@@ -180,13 +181,13 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                     const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}  (:293-294)
                     raw = __builtin_fma(pk, cx.ratio, x - a_new);                  // :282, (X - A_k) + Y_k / mu_k
                     if (MODE == 1) {
-                        const float zf = (float)(pk - cx.inv_mu * y0_of(x));       // :293 with U_0 = Y_0 / mu_0
+                        const float zf = (float)(pk - cx.inv_mu * y0_of(x)) * kUScale;   // :293 with U_0 = Y_0 / mu_0, in units of 128
                         if (t == 0) zz0 += zf * zf; else zz += zf * zf;
                         if (t == 0 || WU) pkf = (float)pk;
                     } else if (t == 0 || RU || WU) {
                         pkf = (float)pk;
                         if (t == 0 || RU) {
-                            const float zf = pkf - uf[t];                          // :293
+                            const float zf = __builtin_fmaf(pkf, kUScale, -uf[t]);  // :293, in units of 128
                             if (t == 0) zz0 += zf * zf; else zz += zf * zf;
                         }
                     }
@@ -338,7 +339,8 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
         if ((i >> 4) <= (j >> 4)) gp[idx] = sG[i * NPAD + j];
     }
     if (MODE != 0) {
-        double zsum = (double)zz0 + ((MODE == 1 || ru) ? (double)zz : 0.0);     // without all of U only the first four frames count
+        // without all of U only the first four frames count; the sums are in units of 128^2 (buf_ld16h)
+        double zsum = ((double)zz0 + ((MODE == 1 || ru) ? (double)zz : 0.0)) * ((double)kUUnscale * (double)kUUnscale);
         for (int off = 32; off; off >>= 1) zsum += __shfl_down(zsum, off);
         __syncthreads();
         if (lane == 0) lds[NPAD * NPAD + wave] = zsum;

@@ -402,31 +402,43 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
     if (tid == 0) st.sweeps = 100 + sweeps;
 }
 
-// With many slabs per window (small batches use many blocks per window) the sum is done by the whole chip first:
-// a block takes 64 matrix entries (lane = entry: coalesced), each of its four waves a quarter of the slabs, and the four
-// partial sums are combined in wave order -- a fixed summation order, so results are reproducible.
-__global__ __launch_bounds__(256) void k_gram_reduce(IalmBuffers b)
+// With many slabs per window (small batches use many blocks per window) the sum is done by the whole chip first: a
+// block of 16 waves takes 64 matrix entries (lane = entry: coalesced rows of a slab), each wave a sixteenth of the slabs
+// with four loads in flight, and the partial sums are combined in a fixed order -- reproducible results.  (One thread per
+// entry walking all slabs, the first version, was a chain of up to 512 dependent cache misses: 32 us for a lone window.)
+__global__ __launch_bounds__(1024) void k_gram_reduce(IalmBuffers b)
 {
     const int w = blockIdx.y, n = b.n;
     if (b.win[w].done) return;
-    __shared__ double part[4][64];
+    __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;
     // the passes only write frame-block pairs ib <= jb
     const bool live = idx < n * n && ((idx / n) >> 4) <= ((idx % n) >> 4);
     double *gp = b.gpart + (int64_t)w * b.nblk * n * n;
-    const int per = (b.nblk + 3) / 4, b0 = wave * per, b1 = min(b0 + per, b.nblk);
-    double acc = 0.0;
-    if (live)
-        for (int bk = b0; bk < b1; ++bk) acc += gp[(int64_t)bk * n * n + idx];
-    part[wave][lane] = acc;
+    const int per = (b.nblk + 15) / 16, b0 = wave * per, b1 = min(b0 + per, b.nblk);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (live) {
+        const int64_t nn = (int64_t)n * n;
+        int bk = b0;
+        for (; bk + 3 < b1; bk += 4) {
+            a0 += gp[(bk + 0) * nn + idx]; a1 += gp[(bk + 1) * nn + idx];
+            a2 += gp[(bk + 2) * nn + idx]; a3 += gp[(bk + 3) * nn + idx];
+        }
+        for (; bk < b1; ++bk) a0 += gp[bk * nn + idx];
+    }
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wave == 0 && live) gp[idx] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (wave == 0 && live) {
+        double acc = 0.0;
+        for (int g = 0; g < 16; ++g) acc += part[g][lane];
+        gp[idx] = acc;
+    }
 }
 
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
 {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 63) / 64, b.nwin), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 63) / 64, b.nwin), dim3(1024), 0, s, b);
 }
 
 template <int NB>

@@ -569,6 +569,22 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
     return SWK_OK;
 }
 
+// Page-locked host memory for the caller's staging buffers: a host -> device copy out of it is one DMA instead of a
+// driver-side staging copy plus a DMA (the FrameQueue drop-in stacks a window's crops into such a buffer).
+int32_t swk_pinned_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes < 1) return SWK_ERR_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return SWK_ERR_NOMEM; }
+    return SWK_OK;
+}
+
+int32_t swk_pinned_free(void *p)
+{
+    if (!p) return SWK_OK;
+    return hipHostFree(p) == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+
 int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags)
 {
     if (!ctx || flags < 0 || flags > 3) return SWK_ERR_ARG;

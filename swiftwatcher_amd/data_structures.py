@@ -140,7 +140,7 @@ class FrameQueue(deque):
         crops = self.get_processed_queue("crop")
         shape = (len(crops),) + crops[0].shape
         if self._staging is None or self._staging.shape != shape:
-            self._staging = np.empty(shape, np.uint8)
+            self._staging = _lib.pinned_empty(shape, np.uint8)      # page-locked: the upload is one DMA
         for i, c in enumerate(crops):
             self._staging[i] = c
         return self._staging

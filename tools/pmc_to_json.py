@@ -10,7 +10,7 @@ import json, re, sys
 
 meas = sys.argv[1]
 summ = json.load(open(meas + "/pmc_summary.json"))
-key = [k for k in summ if "k_ialm_pass_v3<4, 2" in k][0]
+key = [k for k in summ if "k_ialm_pass_m<16, 2>" in k or "k_ialm_pass_v3<4, 2" in k][0]
 c = summ[key]
 probe = open(meas + "/pass_probe.txt").read()
 counted = float(re.search(r"k_probe<0>.*FETCH_SIZE counted B/elt ([0-9.]+)", probe).group(1))
@@ -20,13 +20,13 @@ W, n, P = 128, 64, 89888
 elems = W * n * P
 # the per-dispatch means include the lag launch that finds every window finished (0 bytes): 15 dispatches, 14 live
 live = 14.0 / 15.0
-bench = json.loads(open(meas + "/bench_default.log").read().strip().splitlines()[-1])
+bench = json.loads([l for l in open(meas + "/bench_segment.log") if l.startswith("{")][-1])
 K = bench["config"]["ialm_iters_mean"]
 alg = (bench["roofline"]["bytes_per_element_iteration"] * K - 10.125) / (K - 1.0)
 fetch_kb, write_kb = c["FETCH_SIZE"] / live, c["WRITE_SIZE"] / live
 read_b, write_b = fetch_kb * 1024 * factor, write_kb * 1024
 out = {
-    "kernel": "k_ialm_pass_v3<4,2,true>", "variant": 3, "windows_per_dispatch": W, "n": n, "P": P,
+    "kernel": key.replace("void swk::", ""), "variant": 3, "windows_per_dispatch": W, "n": n, "P": P,
     "FETCH_SIZE_KB_per_live_dispatch": fetch_kb, "WRITE_SIZE_KB_per_live_dispatch": write_kb,
     "fetch_calibration": {"probe": "tools/pass_probe shape 0 (same loads/stores, known 11 B read + 11 B written per element)",
                           "counted_read_B_per_element": counted, "factor": factor,
