@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* at the f32 vector rate (155 measured)
+F64_MATRIX_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 64 cycles per instruction per SIMD (measured) = 32 flop/clk/SIMD at 2.4 GHz
 # algorithmic bytes per matrix element and IALM iteration of the streaming pass:
 #   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
 #   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 written = 21; first = 11;
@@ -58,7 +59,11 @@ def parse():
                     help="time the image_filtering part only (the headline metric then reads 'segment'); for kernel A/Bs")
     ap.add_argument("--full-network", action="store_true", help="A/B: the full 224x224 forward instead of the receptive-field cropped one")
     ap.add_argument("--cls-batch", type=int, default=4096, help="segments per classifier forward")
-    ap.add_argument("--cudnn-benchmark", action="store_true", help="A/B: torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="also time the steps as a two-stage pipeline: the image_filtering part of step i+1 (library stream, "
+                         "worker thread) runs while the classifier works on step i (PyTorch's stream); reported under 'overlapped'")
+    ap.add_argument("--no-cudnn-benchmark", action="store_true",
+                    help="A/B: MIOpen's immediate-mode kernel choice instead of its exhaustive find (the classifier's default)")
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--tune", type=int, default=None, help="A/B: swk_set_pass_tuning flags (variants 4 / 5)")
     ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
@@ -148,8 +153,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     classify = not args.no_classify
-    if args.cudnn_benchmark:
-        torch.backends.cudnn.benchmark = True
+    if args.no_cudnn_benchmark:
+        os.environ["SWK_CUDNN_BENCHMARK"] = "0"
 
     geo = getattr(synthetic, args.size)
     Hc, Wc, n, nwin = geo["Hc"], geo["Wc"], args.n, args.windows
@@ -271,6 +276,49 @@ def main():
         step()
     redo0 = ctx.redo_batches
     dt_max, prof, bpe, net = timed(step)
+    overlapped = None
+    if args.overlap and clf is not None:
+        # Two-stage software pipeline over the SAME K steps: products of step i+1 go to a second set of buffers while
+        # the classifier reads step i's.  The classifier cuts its inputs through a second library context (its own
+        # stream), so the two stages only meet on the GPU's queues.
+        from concurrent.futures import ThreadPoolExecutor
+        ctx2 = _lib.Context(local)
+        slots = []
+        for k in range(2):
+            lab2 = labels if k == 0 else torch.empty_like(labels)
+            seg2 = segs if k == 0 else torch.empty_like(segs)
+            ns2 = nseg if k == 0 else torch.empty_like(nseg)
+            it2 = iters if k == 0 else torch.empty_like(iters)
+            o = _lib.Output(mem=_lib.MEM_DEVICE, seg_cap=seg_cap)
+            o.labels, o.segs, o.nseg, o.iters = lab2.data_ptr(), seg2.data_ptr(), ns2.data_ptr(), it2.data_ptr()
+            slots.append((o, seg2, ns2, lab2, it2))
+        torch.cuda.synchronize()
+
+        def classify_slot(slot):
+            scores, fidx = clf.scores_from_device(ctx2, inp, (Hc, Wc), slot[1], slot[2], seg_cap)
+            keep = torch.max(scores, 1)[1] == 1
+            per_frame = torch.bincount(fidx[keep].to(torch.int64), minlength=F)
+            return int(per_frame.sum().item())
+
+        def pipelined(K):
+            kept = 0
+            with ThreadPoolExecutor(1) as ex:
+                fut = ex.submit(ctx.batch_run_raw, inp, params, slots[0][0])
+                for i in range(K):
+                    fut.result()
+                    if i + 1 < K:
+                        fut = ex.submit(ctx.batch_run_raw, inp, params, slots[(i + 1) & 1][0])
+                    kept = classify_slot(slots[i & 1])
+            return kept
+        pipelined(2)
+        fence()
+        t0 = time.perf_counter()
+        kept_o = pipelined(args.steps)
+        fence()
+        dt_o = swd.max_over_ranks(time.perf_counter() - t0)
+        overlapped = {"value": round(F * args.steps * world / dt_o, 2), "ms_per_step": round(dt_o / args.steps * 1e3, 3),
+                      "kept_last_step": kept_o, "same_kept_as_serial": kept_o == kept_total[0]}
+        ctx2.close()
     # second loop: the image_filtering part alone (same data, same step count)
     seg_only = timed(segment_step) if clf is not None else None
     redo = ctx.redo_batches - redo0
@@ -305,12 +353,25 @@ def main():
                         traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
                 except Exception:
                     traffic = None
+            # the same launches against the f64 matrix pipe: MFMAs per 16-pixel tile = NB x NK (A update) + 4 x NB (NB + 1) / 2
+            # (symmetric Gram), 2 x 16 x 16 x 4 flop each, for every tile of every window-iteration streamed
+            nk, nb = (n + 3) // 4, (n + 15) // 16
+            if variant != 3 or (args.variant and args.variant <= 3):
+                nk = 4 * nb                                   # block-templated kernels run whole 16-frame blocks
+            mfma_per_tile = nb * nk + 2 * nb * (nb + 1)
+            tiles = (P + 15) // 16
+            flop = float(it_host.sum()) * args.steps * tiles * mfma_per_tile * 2048.0
+            f64_tflops = flop / (pass_ms * 1e-3) / 1e12 if pass_ms > 0 else 0.0
             return {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
                     "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
                     "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
                     "pass_variant": variant,
+                    # where the kernel really sits: f64 MFMAs and f64 vector instructions share one execution unit on
+                    # gfx950 (profiles/r2_f64_pipe_probe.txt), so the matrix pipe's share of the launch is a second floor
+                    "f64_matrix_pipe": {"achieved": round(f64_tflops, 2), "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(f64_tflops / F64_MATRIX_PEAK_TFLOPS, 4), "mfma_per_tile": mfma_per_tile},
                     # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
                     # replaces): informational, NOT what "achieved" uses
                     "survey_pricing": {"bytes_per_element_iteration": 33,
@@ -357,6 +418,8 @@ def main():
                 "net_ms_per_step": round(net_ms / args.steps, 3),
                 "segments_per_s_in_network": round(rows / (net_ms * 1e-3), 1) if net_ms > 0 else 0.0}
             so_dt, so_prof, so_bpe, _ = seg_only
+            if overlapped is not None:
+                res["overlapped"] = overlapped
             res["segment_only"] = {"metric": "frames/sec (segment) on 1080p ROI batches", "value": round(total_frames / so_dt, 2),
                                    "ms_per_step": round(so_dt / args.steps * 1e3, 3), "roofline": pass_roofline(so_prof, so_bpe),
                                    "kernel_ms_per_step": kernel_ms(so_prof)}

@@ -36,13 +36,15 @@ TMO=300 step bench_w1_n21 python3 bench.py --no-cpu-baseline --no-classify --win
 TMO=300 step bench_p1 python3 bench.py --no-cpu-baseline --no-classify --size P1 --windows 512
 TMO=300 step bench_p3 python3 bench.py --no-cpu-baseline --no-classify --size P3 --windows 32
 TMO=300 step bench_p3_n21 python3 bench.py --no-cpu-baseline --size P3 --n 21 --windows 96
-TMO=300 step bench_cudnn python3 bench.py --no-cpu-baseline --cudnn-benchmark
+TMO=300 step bench_nofind python3 bench.py --no-cpu-baseline --no-cudnn-benchmark
+TMO=300 step bench_overlap python3 bench.py --no-cpu-baseline --overlap --steps 4
+TMO=300 step bench_groups2 python3 bench.py --no-cpu-baseline --no-classify --groups 2
 TMO=300 step bench_classifier python3 tools/bench_classifier.py
 TMO=300 step bench_framequeue python3 tools/bench_framequeue.py
 TMO=300 step bench_pipeline python3 tools/bench_pipeline.py
 TMO=600 step soak python3 tools/spec_soak.py 30
 echo "[done]"; date
-for f in default segment spec_off v2 v3 n21 n49 host w1 w1_n21 p1 p3 p3_n21 cudnn; do echo "== $f"; grep "^{" $out/bench_$f.log | tail -n 1 | cut -c1-330; done
+for f in default segment spec_off v2 v3 n21 n49 host w1 w1_n21 p1 p3 p3_n21 nofind overlap groups2; do echo "== $f"; grep "^{" $out/bench_$f.log | tail -n 1 | cut -c1-330; done
 tail -n 1 $out/bench_classifier.log | cut -c1-600
 tail -n 1 $out/bench_framequeue.log | cut -c1-900
 tail -n 3 $out/bench_pipeline.log | cut -c1-600
