@@ -214,6 +214,14 @@ int32_t swk_nhwc_bias_relu_place(void *stream, const float *src, int32_t n, int3
                                  int32_t crop_x, int32_t h, int32_t w, const float *bias, float *dst, int32_t dH, int32_t dW,
                                  int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h, int32_t w, int32_t c, float *dst);
+/* conv1x1_bias_relu_place: a 1 x 1 convolution fused with everything up to the next layer's tile (the squeeze and expand1x1
+ * convolutions of a Fire module), on the f32 matrix cores:
+ *   dst[n][off_y+y][off_x+x][c_off+co] = max(sum_ci src[n][crop_y+y][crop_x+x][ci] * weight[co][ci] + bias[co], 0)
+ * src [n][sh][sw][cin] (cin a multiple of 16), weight [cout][cin] (a Conv2d weight with a 1 x 1 kernel), cout <= 256,
+ * dst [n][dH][dW][dC]. */
+int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t crop_y,
+                                         int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
+                                         float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size

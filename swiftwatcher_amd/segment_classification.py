@@ -10,7 +10,7 @@ Differences from the reference, all deliberate:
     Dropout(0.5) is live and its decisions are random; eval mode is the deterministic definition;
   * segments are classified in one batch instead of one 602 KB H2D copy + sync per segment;
   * by default only the part of each feature map the 24x24 patch can influence is evaluated
-    (CroppedSqueezeNet10, 4.7x fewer MACs, same arithmetic per output); cropped=False runs the full network.
+    (CroppedSqueezeNet10, 5.7x fewer MACs: 0.128 instead of 0.733 G per segment, same arithmetic per output); cropped=False runs the full network.
 """
 import ctypes
 import os
@@ -85,7 +85,7 @@ class CroppedSqueezeNet10:
         -> fire2..4: 10, 12, 14 -> pool 8x8 (9..16 of 27) -> fire5..8: 10, 12, 14, 16 -> pool 9x9 (2..10 of 13)
         -> fire9 11x11 -> 1x1 head + ReLU on 11x11, plus the head's constant ring, / 169.
 
-    Same arithmetic per output as the full network (0.156 instead of 0.733 GMAC per segment); results differ from
+    Same arithmetic per output as the full network (0.128 instead of 0.733 GMAC per segment); results differ from
     it only by float32 summation order inside the convolution kernels and in the final average."""
 
     IN_LO, IN_HI = 92, 131            # rows/cols of the 224-pixel input the tile covers (patch at 100..123)
@@ -165,6 +165,8 @@ class CroppedSqueezeNet10:
         self.memory_format = torch.channels_last if want else torch.contiguous_format
         if self.memory_format == torch.channels_last:
             model.to(memory_format=torch.channels_last)
+        # 1x1 convolutions by the library's own fused kernel (SWK_FUSED_1X1=0: through MIOpen + the placement kernel)
+        self.fused_1x1 = os.environ.get("SWK_FUSED_1X1", "1") == "1"
 
     def macs_per_segment(self):
         """Multiply-accumulates the convolutions of one forward execute per segment: (executed, useful).  "executed"
@@ -276,6 +278,15 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_bias_relu_place failed (%d)" % rc)
 
+        def conv1x1(src, crop, size, conv, dest, off, c_off):
+            src = nhwc(src)
+            wgt = conv.weight.reshape(conv.out_channels, conv.in_channels)       # 1 x 1 kernel: same memory in both layouts
+            rc = lib.swk_nhwc_conv1x1_bias_relu_place(stream, src.data_ptr(), k, src.shape[2], src.shape[3], src.shape[1], crop, crop,
+                                                      size, size, wgt.data_ptr(), conv.bias.data_ptr(), conv.out_channels,
+                                                      dest.data_ptr(), dest.shape[2], dest.shape[3], dest.shape[1], off, off, c_off)
+            if rc:
+                raise RuntimeError("swk_nhwc_conv1x1_bias_relu_place failed (%d)" % rc)
+
         def pool(src, dst):
             rc = lib.swk_nhwc_maxpool3s2(stream, src.data_ptr(), k, src.shape[2], src.shape[3], src.shape[1], dst.data_ptr())
             if rc:
@@ -297,16 +308,23 @@ class CroppedSqueezeNet10:
                 pi += 1
                 continue
             sq = bufs[j][:k]
-            place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
-            e3 = conv2d(sq, layer.expand3x3.weight, None)
-            e1 = conv2d(sq, layer.expand1x1.weight, None)
             c, cn = crop
             c1 = layer.expand1x1.out_channels
             if live[j] is not None:
                 dest, doff = live[j][:k], 0
             else:
                 dest, doff = bufs[j + 1][:k], self.plan[j + 1][3]
-            place(e1, layer.expand1x1.bias, dest, c, cn, doff, 0)
+            if self.fused_1x1:
+                # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
+                # (csrc/cnn_conv1x1.hip); only the 3x3 expand stays with MIOpen
+                conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
+                e3 = conv2d(sq, layer.expand3x3.weight, None)
+                conv1x1(sq, c, cn, layer.expand1x1, dest, doff, 0)
+            else:
+                place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
+                e3 = conv2d(sq, layer.expand3x3.weight, None)
+                e1 = conv2d(sq, layer.expand1x1.weight, None)
+                place(e1, layer.expand1x1.bias, dest, c, cn, doff, 0)
             place(e3, layer.expand3x3.bias, dest, 0, cn, doff, c1)
             x = dest
         s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))

@@ -294,3 +294,46 @@ def test_gpu_model_pt_scores_and_decisions(golden_dir):
         sgm.segment_image = c
     kept = clf(segs)
     assert len(kept) == int(keep.sum()) and [s.label for s in kept] == list(range(1, len(kept) + 1))
+
+
+@pytest.mark.gpu
+def test_fused_conv1x1_kernel_against_torch():
+    """swk_nhwc_conv1x1_bias_relu_place (convolution + bias + ReLU + placement on the f32 matrix cores) against
+    torch.nn.functional.conv2d on the shapes the Fire modules use and on ragged ones (pixel count not a multiple of 32,
+    output channels not a multiple of 32, crop inside the source, channel offset in the destination).  float32 in a
+    different summation order: 2e-5 relative to the output scale."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    cases = [  # n, cin, cout, sh, crop, size, dH, off, dC, c_off
+        (5, 96, 16, 8, 0, 8, 12, 2, 16, 0), (3, 128, 32, 14, 0, 14, 16, 1, 32, 0), (7, 256, 48, 12, 0, 12, 14, 1, 48, 0),
+        (4, 512, 64, 9, 0, 9, 13, 2, 64, 0), (6, 16, 64, 12, 1, 10, 10, 0, 128, 0), (3, 32, 128, 16, 1, 14, 17, 0, 256, 0),
+        (2, 48, 192, 14, 1, 12, 12, 0, 384, 0), (3, 64, 256, 18, 1, 16, 19, 2, 512, 0), (1, 64, 200, 7, 2, 3, 5, 1, 260, 60),
+        (9, 16, 1, 5, 0, 5, 5, 0, 4, 3)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, cin, cout, sh, crop, size, dH, off, dC, c_off in cases:
+        x = torch.randn((n, cin, sh, sh), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wgt = (torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5).to(dev)
+        bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+        dst = torch.full((n, dC, dH, dH), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        exp = dst.clone()
+        y = torch.relu(torch.nn.functional.conv2d(x[:, :, crop:crop + size, crop:crop + size], wgt, bias))
+        exp[:, c_off:c_off + cout, off:off + size, off:off + size] = y
+        torch.cuda.synchronize()
+        rc = lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), n, sh, sh, cin, crop, crop, size, size,
+                                                  wgt.reshape(cout, cin).contiguous().data_ptr(), bias.data_ptr(), cout,
+                                                  dst.data_ptr(), dH, dH, dC, off, off, c_off)
+        assert rc == 0, (rc, n, cin, cout)
+        torch.cuda.synchronize()
+        scale = float(y.abs().max()) + 1e-6
+        err = float((dst - exp).abs().max())
+        assert err <= 2e-5 * max(scale, 1.0), (err, scale, n, cin, cout)
+        # nothing outside the placed block was touched
+        mask = torch.ones_like(dst, dtype=torch.bool)
+        mask[:, c_off:c_off + cout, off:off + size, off:off + size] = False
+        assert bool((dst[mask] == -7.0).all())
+    # bad arguments are refused, not launched
+    assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 4, 4, 24, 0, 0, 4, 4, wgt.data_ptr(), bias.data_ptr(), 8,
+                                                dst.data_ptr(), 4, 4, 8, 0, 0, 0) != 0          # cin not a multiple of 16
