@@ -310,7 +310,7 @@ def test_fused_conv1x1_kernel_against_torch():
     cases = [  # n, cin, cout, sh, crop, size, dH, off, dC, c_off
         (5, 96, 16, 8, 0, 8, 12, 2, 16, 0), (3, 128, 32, 14, 0, 14, 16, 1, 32, 0), (7, 256, 48, 12, 0, 12, 14, 1, 48, 0),
         (4, 512, 64, 9, 0, 9, 13, 2, 64, 0), (6, 16, 64, 12, 1, 10, 10, 0, 128, 0), (3, 32, 128, 16, 1, 14, 17, 0, 256, 0),
-        (2, 48, 192, 14, 1, 12, 12, 0, 384, 0), (3, 64, 256, 18, 1, 16, 19, 2, 512, 0), (1, 64, 200, 7, 2, 3, 5, 1, 260, 60),
+        (2, 48, 192, 14, 1, 12, 12, 0, 384, 0), (3, 64, 256, 18, 1, 16, 19, 2, 512, 0), (1, 64, 96, 7, 2, 3, 5, 1, 160, 60),
         (9, 16, 1, 5, 0, 5, 5, 0, 4, 3)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for n, cin, cout, sh, crop, size, dH, off, dC, c_off in cases:

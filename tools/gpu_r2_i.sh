@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r2i; mkdir -p $out
+step() { name=$1; shift; echo "== $name"; date; timeout -k 10 "$TMO" "$@" > $out/$name.log 2>&1; rc=$?; echo "$name rc=$rc"; tail -n 8 $out/$name.log | cut -c1-700; if [ $rc -ge 124 ]; then exit $rc; fi; }
+TMO=600 step t_cls python3 -m pytest tests/test_classifier.py -m gpu -q -x --durations=5
+TMO=300 step bench_fused python3 bench.py --no-cpu-baseline
+SWK_FUSED_1X1=0 TMO=300 step bench_unfused python3 bench.py --no-cpu-baseline
+TMO=300 step bench_fused2 python3 bench.py --no-cpu-baseline
