@@ -223,6 +223,14 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 
+/* conv3x3_bias_relu_place: the 3 x 3 expand convolution of a Fire module as a VALID convolution over the t x t squeeze tile
+ * (the tile carries the halo), fused with bias, ReLU and the placement behind the expand1x1 channels:
+ *   dst[n][off_y+y][off_x+x][c_off+co] = max(sum src[n][y+dy][x+dx][ci] * W[co][ci][dy][dx] + bias[co], 0),  y, x < t - 2
+ * src [n][t][t][cin] (cin a multiple of 16); weight_t = the Conv2d weight re-laid as [dy][dx][ci][co]; cout <= 256. */
+int32_t swk_nhwc_conv3x3_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight_t,
+                                         const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y,
+                                         int32_t off_x, int32_t c_off);
+
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size
  * n_prev + n_curr, row-major.  Centroids are (row, col) float64 pairs; prev_hist0 = centroid of the first

@@ -167,6 +167,8 @@ class CroppedSqueezeNet10:
             model.to(memory_format=torch.channels_last)
         # 1x1 convolutions by the library's own fused kernel (SWK_FUSED_1X1=0: through MIOpen + the placement kernel)
         self.fused_1x1 = os.environ.get("SWK_FUSED_1X1", "1") == "1"
+        self.fused_3x3 = os.environ.get("SWK_FUSED_3X3", "1") == "1"
+        self._wt3 = {}
 
     def macs_per_segment(self):
         """Multiply-accumulates the convolutions of one forward execute per segment: (executed, useful).  "executed"
@@ -287,6 +289,18 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_conv1x1_bias_relu_place failed (%d)" % rc)
 
+        def conv3x3(src, j, conv, dest, off, c_off):
+            src = nhwc(src)
+            wt = self._wt3.get(j)
+            if wt is None:       # [co][ci][3][3] -> [tap][ci][co], once per layer
+                wt = self._wt3[j] = conv.weight.detach().permute(2, 3, 1, 0).contiguous(memory_format=torch.contiguous_format)
+            assert src.shape[2] == src.shape[3]
+            rc = lib.swk_nhwc_conv3x3_bias_relu_place(stream, src.data_ptr(), k, src.shape[2], src.shape[1], wt.data_ptr(),
+                                                      conv.bias.data_ptr(), conv.out_channels, dest.data_ptr(), dest.shape[2],
+                                                      dest.shape[3], dest.shape[1], off, off, c_off)
+            if rc:
+                raise RuntimeError("swk_nhwc_conv3x3_bias_relu_place failed (%d)" % rc)
+
         def pool(src, dst):
             rc = lib.swk_nhwc_maxpool3s2(stream, src.data_ptr(), k, src.shape[2], src.shape[3], src.shape[1], dst.data_ptr())
             if rc:
@@ -316,16 +330,18 @@ class CroppedSqueezeNet10:
                 dest, doff = bufs[j + 1][:k], self.plan[j + 1][3]
             if self.fused_1x1:
                 # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
-                # (csrc/cnn_conv1x1.hip); only the 3x3 expand stays with MIOpen
+                # (csrc/cnn_conv1x1.hip)
                 conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
-                e3 = conv2d(sq, layer.expand3x3.weight, None)
                 conv1x1(sq, c, cn, layer.expand1x1, dest, doff, 0)
             else:
                 place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
-                e3 = conv2d(sq, layer.expand3x3.weight, None)
                 e1 = conv2d(sq, layer.expand1x1.weight, None)
                 place(e1, layer.expand1x1.bias, dest, c, cn, doff, 0)
-            place(e3, layer.expand3x3.bias, dest, 0, cn, doff, c1)
+            if self.fused_3x3:
+                # the 3x3 expand (valid convolution over the squeeze tile) likewise (csrc/cnn_conv3x3.hip)
+                conv3x3(sq, j, layer.expand3x3, dest, doff, c1)
+            else:
+                place(conv2d(sq, layer.expand3x3.weight, None), layer.expand3x3.bias, dest, 0, cn, doff, c1)
             x = dest
         s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
         return (s + self.ring_sum) / self.n_pos

@@ -337,3 +337,42 @@ def test_fused_conv1x1_kernel_against_torch():
     # bad arguments are refused, not launched
     assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 4, 4, 24, 0, 0, 4, 4, wgt.data_ptr(), bias.data_ptr(), 8,
                                                 dst.data_ptr(), 4, 4, 8, 0, 0, 0) != 0          # cin not a multiple of 16
+
+
+@pytest.mark.gpu
+def test_fused_conv3x3_kernel_against_torch():
+    """swk_nhwc_conv3x3_bias_relu_place (valid 3 x 3 convolution over the squeeze tile + bias + ReLU + placement behind the
+    expand1x1 channels, weights streamed through LDS) against torch.nn.functional.conv2d: every (channels, tile) shape the
+    Fire modules use, batches whose pixel count is not a multiple of the row tiles, and a channel count that is not a
+    multiple of 32."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    cases = [  # n, cin, cout, t, dH, off, dC, c_off
+        (7, 16, 64, 12, 10, 0, 128, 64), (5, 16, 64, 14, 12, 0, 128, 64), (3, 32, 128, 16, 17, 1, 256, 128),
+        (9, 32, 128, 12, 10, 0, 256, 128), (2, 48, 192, 14, 12, 0, 384, 192), (3, 48, 192, 16, 14, 0, 384, 192),
+        (2, 64, 256, 18, 19, 2, 512, 256), (5, 64, 256, 13, 11, 0, 512, 256), (1, 16, 40, 5, 4, 1, 44, 4), (300, 16, 64, 4, 2, 0, 64, 0)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, cin, cout, t, dH, off, dC, c_off in cases:
+        x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wgt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+        bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+        wt = wgt.permute(2, 3, 1, 0).contiguous()
+        dst = torch.full((n, dC, dH, dH), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        exp = dst.clone()
+        y = torch.relu(torch.nn.functional.conv2d(x, wgt, bias))
+        o = t - 2
+        exp[:, c_off:c_off + cout, off:off + o, off:off + o] = y
+        torch.cuda.synchronize()
+        rc = lib.swk_nhwc_conv3x3_bias_relu_place(stream, x.data_ptr(), n, t, cin, wt.data_ptr(), bias.data_ptr(), cout,
+                                                  dst.data_ptr(), dH, dH, dC, off, off, c_off)
+        assert rc == 0, (rc, n, cin, cout, t)
+        torch.cuda.synchronize()
+        scale = max(float(y.abs().max()), 1.0)
+        err = float((dst - exp).abs().max())
+        assert err <= 2e-5 * scale, (err, scale, n, cin, cout, t)
+        mask = torch.ones_like(dst, dtype=torch.bool)
+        mask[:, c_off:c_off + cout, off:off + o, off:off + o] = False
+        assert bool((dst[mask] == -7.0).all())
