@@ -67,12 +67,23 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
             const float4 c0 = a0, c1 = a1;
             if (kb + 16 < cin) { a0 = *(const float4 *)(p + kb + 16); a1 = *(const float4 *)(p + kb + 20); }
             const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            // B operands of step i + 1 are read from LDS while step i multiplies (two register sets, scheduling fences:
+            // left alone the compiler reads each operand right before its MFMA and the wave waits out the LDS latency)
             const float *wrow = lds + (kb + 8 * hh) * PITCH + r;
+            float bw[2][NBLK];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int nb = 0; nb < NBLK; ++nb) bw[0][nb] = wrow[32 * nb];
 #pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wrow[i * PITCH + 32 * nb], acc[nb], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) {
+                if (i < 7) {
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i & 1][nb], acc[nb], 0, 0, 0);
+                if (i < 7) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NBLK, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NBLK, 0);
+            }
         }
         // ---- bias + ReLU + placement straight from the accumulator layout ----
 #pragma unroll

@@ -107,20 +107,28 @@ __global__ __launch_bounds__(512) void k_conv3x3_relu_place(const float *__restr
                 for (int q = 0; q < RT; ++q) { a0[q] = *(const float4 *)(p[q] + aoff); a1[q] = *(const float4 *)(p[q] + aoff + 4); }
                 chunk_load(cn);
             }
-            // ---- 8 MFMA steps x NBLK column blocks x RT row tiles on the current chunk ----
+            // ---- 8 MFMA steps x NBLK column blocks x RT row tiles on the current chunk.  The B operands of step i + 1 are
+            //      read from LDS while step i multiplies (two register sets); left to itself the compiler reads each
+            //      operand right before the MFMA that needs it and the wave waits out the LDS latency every two MFMAs ----
             const float *wrow = ((c & 1) ? wb1 : wb0) + 8 * hh * PITCH + r;
+            float bw[2][NBLK];
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) bw[0][nb] = wrow[32 * nb];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float bw[NBLK];
+                if (i < 7) {
 #pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) bw[nb] = wrow[i * PITCH + 32 * nb];
+                    for (int nb = 0; nb < NBLK; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
+                }
 #pragma unroll
                 for (int q = 0; q < RT; ++q) {
                     const float av = i < 4 ? (i == 0 ? c0[q].x : i == 1 ? c0[q].y : i == 2 ? c0[q].z : c0[q].w)
                                            : (i == 4 ? c1[q].x : i == 5 ? c1[q].y : i == 6 ? c1[q].z : c1[q].w);
 #pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb) acc[q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[nb], acc[q][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NBLK; ++nb) acc[q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[i & 1][nb], acc[q][nb], 0, 0, 0);
                 }
+                if (i < 7) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NBLK, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NBLK * RT, 0);
             }
             // the other buffer is the one chunk c - 1 was read from: every wave left it at the last barrier
             if (c + 1 < nchunks) chunk_store((c & 1) ? wb0 : wb1);

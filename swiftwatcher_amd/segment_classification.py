@@ -185,7 +185,8 @@ class CroppedSqueezeNet10:
             t = tile.shape[2] + pad[0] + pad[1]
             sq, e1, e3 = layer.squeeze, layer.expand1x1, layer.expand3x3
             executed += n * n * sq.out_channels * sq.in_channels
-            executed += t * t * e1.out_channels * e1.in_channels + (t - 2) ** 2 * e3.out_channels * e3.in_channels * 9
+            e1_side = crop[1] if getattr(self, "fused_1x1", False) else t      # the fused kernel only computes the rows that are used
+            executed += e1_side * e1_side * e1.out_channels * e1.in_channels + (t - 2) ** 2 * e3.out_channels * e3.in_channels * 9
             useful += n * n * sq.out_channels * sq.in_channels
             useful += crop[1] ** 2 * (e1.out_channels * e1.in_channels + e3.out_channels * e3.in_channels * 9)
             last_n = crop[1]
