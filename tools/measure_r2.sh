@@ -8,6 +8,7 @@ part=${1:-a}
 mkdir -p $out
 step() { name=$1; shift; echo "[$name]"; date; timeout -k 10 "$TMO" "$@" > $out/$name.log 2>&1; rc=$?; echo "$name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi; }
 if [ "$part" = "a" ]; then
+TMO=400 step bench_prewarm python3 bench.py --no-cpu-baseline --steps 2 --warmup 1     # MIOpen find results into the user db: the trace below holds steady-state kernels
 TMO=500 step stats rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv; rm -rf $out/stats
 echo "[pmc]"; date
