@@ -218,10 +218,15 @@ int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h
  * convolutions of a Fire module), on the f32 matrix cores:
  *   dst[n][off_y+y][off_x+x][c_off+co] = max(sum_ci src[n][crop_y+y][crop_x+x][ci] * weight[co][ci] + bias[co], 0)
  * src [n][sh][sw][cin] (cin a multiple of 16), weight [cout][cin] (a Conv2d weight with a 1 x 1 kernel), cout <= 256,
- * dst [n][dH][dW][dC]. */
+ * dst [n][dH][dW][dC]; cout, dC and c_off multiples of 4 (the kernel stores four channels at a time), src and dst 16-byte
+ * aligned. */
 int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t crop_y,
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
+
+/* Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the
+ * 1 x 1 kernel (0 = deepest that fits, 1 = one 16-channel chunk in flight). */
+int32_t swk_set_cnn_tuning(int32_t knob, int32_t value);
 
 /* conv3x3_bias_relu_place: the 3 x 3 expand convolution of a Fire module as a VALID convolution over the t x t squeeze tile
  * (the tile carries the halo), fused with bias, ReLU and the placement behind the expand1x1 channels:
@@ -230,6 +235,17 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
 int32_t swk_nhwc_conv3x3_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight_t,
                                          const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y,
                                          int32_t off_x, int32_t c_off);
+
+/* The same convolution by Winograd's F(2x2, 3x3) on the f32 matrix cores (2.25 x fewer multiplies; csrc/cnn_wino3x3.hip) for
+ * the Fire shapes cin = cout / 4 in {32, 48, 64}; other shapes are refused (SWK_ERR_ARG) and take the direct kernel above.
+ * weight_w = the filter transform G g G^T in the kernel's operand layout, made once per layer by
+ * swk_winograd_f2x2_3x3_weights (host code, float64 then rounded) from the Conv2d weight [cout][cin][3][3] into
+ * out[16 * cin * 32 * ceil(cout / 32)].  Results differ from the direct kernel by float32 rounding of the transform
+ * (<= 1e-5 of the output scale, tests/test_classifier.py).  cout, dC, c_off multiples of 4; src, dst, weight_w 16-byte aligned. */
+int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t cin, float *out);
+int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight_w,
+                                                  const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC,
+                                                  int32_t off_y, int32_t off_x, int32_t c_off);
 
 /* ---- host-side tracker kernels (no GPU, no context): SURVEY section 8f rank 1 -----------------------
  * Cost matrix of SegmentTracker.formulate_cost_matrix (segment_tracking.py:46-102, 179-254): square, size

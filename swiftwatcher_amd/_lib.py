@@ -88,8 +88,11 @@ _SIGS = {
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_nhwc_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6),
+    "swk_set_cnn_tuning": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     "swk_nhwc_conv1x1_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p] + [ctypes.c_int32] * 6),
     "swk_nhwc_conv3x3_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p] + [ctypes.c_int32] * 6),
+    "swk_nhwc_conv3x3_winograd_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p] + [ctypes.c_int32] * 6),
+    "swk_winograd_f2x2_3x3_weights": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_nhwc_maxpool3s2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_segment_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),

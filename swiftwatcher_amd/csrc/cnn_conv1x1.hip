@@ -8,18 +8,21 @@
 // the convolution's output, the implicit-GEMM kernel, and k_bias_relu_place reading that output again to write the tile --
 // and the expand convolution ran over the whole squeeze tile although only its centre is used.
 //
-// A 1x1 convolution in channels-last layout is a plain GEMM, rows = pixels (n * h * w of them), K = input channels,
-// N = output channels.  v_mfma_f32_32x32x2_f32 (exact float32: a k-ordered fmaf chain, 64 cycles per instruction per SIMD,
-// the f32 matrix peak of 157 TFLOP/s): lane l supplies A[row l & 31][k = l >> 5] and B[k = l >> 5][col l & 31].
-//   * a wave owns 32 pixels.  A lane (row r, half h) loads 8 consecutive input channels kb + 8h .. kb + 8h + 7 of its
-//     pixel (two 16-byte loads of one 32-byte piece of the pixel's channel vector) and feeds them to 8 MFMA steps; step i
-//     multiplies channels {kb + i, kb + 8 + i} -- a permuted k order, matched by reading weight row kb + 8h + i for half h.
+// A 1x1 convolution in channels-last layout is a plain GEMM, K = input channels.  v_mfma_f32_32x32x2_f32 (exact float32:
+// a k-ordered fmaf chain, 64 cycles per instruction per SIMD, the f32 matrix peak of 157 TFLOP/s) computes D = A B with lane l
+// supplying A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].  Here the WEIGHTS are the A operand (i = output channel)
+// and the PIXELS the B operand (j = pixel), so that an accumulator register quad holds four consecutive output channels of
+// the lane's own pixel (i = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), j = l & 31): the epilogue is 4 float4 stores per 32
+// channels, addressed by the lane's own pixel, no transposition.
+//   * a wave owns 32 pixels.  A lane (pixel r, half h) loads KC / 2 consecutive input channels kb + (KC/2) h .. of its
+//     pixel as float4s -- with KC = 32 the two halves fetch one whole 128-byte line of the pixel's channel vector at once, so a
+//     line is requested once (with 16-channel chunks it was requested two to four times, spaced by thousands of cycles, and the
+//     eight waves' lines do not survive that long in L1).  Step i multiplies channels {kb + i, kb + KC/2 + i}: a permuted k
+//     order, matched by reading weight row kb + (KC/2) h + i for half h.
+//   * D such chunks are in flight per lane (a register ring), and the ring runs on into the wave's NEXT row tile: neither a
+//     tile's first multiply nor its epilogue waits for memory.
 //   * the weights (at most 512 x 64 or 64 x 256 floats) sit transposed in LDS, [ci][co] with pitch N + 1: the staging
-//     reads W coalesced along ci and writes conflict-free, and a B-operand read is 32 consecutive floats per half.
-//   * accumulators: N / 32 tiles of 16 registers; bias, ReLU and the strided store happen from the accumulator layout
-//     (col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)): every store instruction writes two 128-byte pieces.
-//   * the next 16 input channels are loaded while the current ones are multiplied (8 x N / 32 MFMAs = 512 .. 4096 cycles
-//     per 32 bytes per lane: the loads are far from the critical path).
+//     reads W coalesced along ci and writes conflict-free, and an operand read is 32 consecutive floats per half.
 // Launched on the CALLER's stream (PyTorch's current stream), like the other glue kernels (cnn_aux.hip).
 #include "swk_internal.h"
 
@@ -27,92 +30,152 @@ namespace swk {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-template <int NBLK>
+template <int NBLK, int KC, int D>
 __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restrict__ src, int64_t rows, int sh, int sw, int cin, int crop_y,
                                                             int crop_x, int h, int w, const float *__restrict__ wgt, const float *__restrict__ bias,
                                                             int cout, float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
-    constexpr int NP = 32 * NBLK, PITCH = NP + 1;
-    extern __shared__ float lds[];                 // weights [cin][PITCH], then 16 x 32 destination row offsets
+    constexpr int NP = 32 * NBLK, PITCH = NP + 1, KH = KC / 2, NV = KH / 4;
+    extern __shared__ float lds[];                 // weights [cin][PITCH], then the bias padded to NP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    int64_t *rowoff = (int64_t *)(lds + ((cin * PITCH + 1) & ~1)) + wave * 32;
-    // ---- weights, transposed: coalesced along ci in W[co][ci], conflict-free in LDS ----
-    for (int i = tid; i < cin * NP; i += 512) {
-        const int co = i / cin, ci = i - co * cin;
-        lds[ci * PITCH + co] = co < cout ? wgt[(int64_t)co * cin + ci] : 0.0f;
-    }
-    __syncthreads();
-    float bv[NBLK];
-#pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) bv[nb] = nb * 32 + r < cout ? bias[nb * 32 + r] : 0.0f;
-
+    float *lbias = lds + ((cin * PITCH + 3) & ~3);
     const int hw = h * w;
-    const int64_t ntiles = (rows + 31) >> 5;
-    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
-        const int64_t m = tile * 32 + r;
+    const int64_t ntiles = (rows + 31) >> 5, stride = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+
+    // source pointer and destination offset of this lane's pixel in a row tile (rows past the end repeat the last one)
+    auto locate = [&](int64_t t, int64_t &ro) -> const float * {
+        const int64_t m = t * 32 + r;
         const bool valid = m < rows;
         const int64_t mm = valid ? m : rows - 1;
         const int64_t b = mm / hw;
         const int rem = (int)(mm - b * hw);
         const int y = rem / w, x = rem - y * w;
-        const float *p = src + ((b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + 8 * hh;
-        if (hh == 0) rowoff[r] = valid ? ((b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off : -1;
+        ro = valid ? ((b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off : -1;
+        return src + ((b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + KH * hh;
+    };
+    float4 a[D][NV];
+    int64_t ro = -1, ro_next = -1;
+    const float *p = src, *pn = src;
+    if (tile < ntiles) {           // the first pieces leave before the weights are staged
+        p = locate(tile, ro);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) a[d][v] = *(const float4 *)(p + KC * d + 4 * v);
+    }
+    // ---- weights, transposed: coalesced along ci in W[co][ci], conflict-free in LDS ----
+    for (int i = tid; i < cin * NP; i += 512) {
+        const int co = i / cin, ci = i - co * cin;
+        lds[ci * PITCH + co] = co < cout ? wgt[(int64_t)co * cin + ci] : 0.0f;
+    }
+    if (tid < NP) lbias[tid] = tid < cout ? bias[tid] : 0.0f;
+    __syncthreads();
+
+    for (; tile < ntiles; tile += stride) {
+        const bool more = tile + stride < ntiles;
+        if (more) pn = locate(tile + stride, ro_next);
         f16v acc[NBLK];
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
-        float4 a0 = *(const float4 *)p, a1 = *(const float4 *)(p + 4);
-        for (int kb = 0; kb < cin; kb += 16) {
-            const float4 c0 = a0, c1 = a1;
-            if (kb + 16 < cin) { a0 = *(const float4 *)(p + kb + 16); a1 = *(const float4 *)(p + kb + 20); }
-            const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            // B operands of step i + 1 are read from LDS while step i multiplies (two register sets, scheduling fences:
-            // left alone the compiler reads each operand right before its MFMA and the wave waits out the LDS latency)
-            const float *wrow = lds + (kb + 8 * hh) * PITCH + r;
-            float bw[2][NBLK];
+        for (int kb = 0; kb < cin; kb += KC * D) {
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) bw[0][nb] = wrow[32 * nb];
+            for (int d = 0; d < D; ++d) {
+                const int k0 = kb + KC * d;
+                float av[KH];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i < 7) {
+                for (int v = 0; v < NV; ++v) { av[4 * v] = a[d][v].x; av[4 * v + 1] = a[d][v].y; av[4 * v + 2] = a[d][v].z; av[4 * v + 3] = a[d][v].w; }
+                const int kn = k0 + KC * D;                      // the chunk that takes this ring slot next
+                if (kn < cin) {
 #pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
+                    for (int v = 0; v < NV; ++v) a[d][v] = *(const float4 *)(p + kn + 4 * v);
+                } else if (more) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) a[d][v] = *(const float4 *)(pn + kn - cin + 4 * v);
                 }
+                // weight operands of step i + 1 are read from LDS while step i multiplies (two register sets, scheduling
+                // fences: left alone the compiler reads each operand right before its MFMA and the wave waits out the LDS latency)
+                const float *wrow = lds + (k0 + KH * hh) * PITCH + r;
+                float bw[2][NBLK];
 #pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i & 1][nb], acc[nb], 0, 0, 0);
-                if (i < 7) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NBLK, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NBLK, 0);
+                for (int nb = 0; nb < NBLK; ++nb) bw[0][nb] = wrow[32 * nb];
+#pragma unroll
+                for (int i = 0; i < KH; ++i) {
+                    if (i < KH - 1) {
+#pragma unroll
+                        for (int nb = 0; nb < NBLK; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[i & 1][nb], av[i], acc[nb], 0, 0, 0);
+                    if (i < KH - 1) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NBLK, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NBLK, 0);
+                }
             }
         }
-        // ---- bias + ReLU + placement straight from the accumulator layout ----
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t ro = rowoff[(e & 3) + 8 * (e >> 2) + 4 * hh];          // written by this wave's own lanes: in order
-            if (ro < 0) continue;
+        // ---- bias + ReLU + placement: register quads = four consecutive output channels of the lane's pixel ----
+        if (ro >= 0) {
+            float *o = dst + ro + 4 * hh;
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb)
-                if (nb * 32 + r < cout) dst[ro + nb * 32 + r] = fmaxf(acc[nb][e] + bv[nb], 0.0f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nb * 32 + 8 * g;
+                    if (c + 4 * hh < cout) {
+                        const float4 b4 = *(const float4 *)(lbias + c + 4 * hh);
+                        float4 v;
+                        v.x = fmaxf(acc[nb][4 * g] + b4.x, 0.0f);
+                        v.y = fmaxf(acc[nb][4 * g + 1] + b4.y, 0.0f);
+                        v.z = fmaxf(acc[nb][4 * g + 2] + b4.z, 0.0f);
+                        v.w = fmaxf(acc[nb][4 * g + 3] + b4.w, 0.0f);
+                        *(float4 *)(o + c) = v;
+                    }
+                }
         }
+        p = pn;
+        ro = ro_next;
     }
 }
 
-template <int NBLK>
-static int launch_conv1x1(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
-                          const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
+template <int NBLK, int KC, int D>
+static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
+                            const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
-    const size_t lds = (size_t)((cin * (32 * NBLK + 1) + 1) & ~1) * sizeof(float) + 16 * 32 * sizeof(int64_t);
+    const size_t lds = (size_t)(((cin * (32 * NBLK + 1) + 3) & ~3) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
     if (lds > 160 * 1024 - 256) return SWK_ERR_CAPACITY;
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + 7) / 8;
     const int64_t cap = lds > 80 * 1024 ? 256 : 512;          // one or two 512-thread workgroups per CU, persistent over the row tiles
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK>), dim3((unsigned)blocks), dim3(512), lds, s, src, rows, sh, sw, cin, crop_y, crop_x, h, w,
-                       wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D>), dim3((unsigned)blocks), dim3(512), lds, s, src, rows, sh, sw, cin, crop_y, crop_x, h,
+                       w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
+
+int g_conv1x1_ring = 0;          // 0: deepest ring that fits and divides the chunk count; 1: one chunk in flight (A/B knob)
+
+#define SWK_C1_ARGS s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
+template <int NBLK>
+static int launch_conv1x1(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
+                          const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
+{
+    if (cin % 32 == 0) {           // whole 128-byte lines per pixel and chunk
+        const int n = cin / 32, dmax = g_conv1x1_ring == 1 ? 1 : NBLK >= 6 ? 2 : 4;          // ring registers: 16 D; accumulators: 16 NBLK
+        const int d = dmax >= 4 && n % 4 == 0 ? 4 : dmax >= 3 && n % 3 == 0 ? 3 : dmax >= 2 && n % 2 == 0 ? 2 : 1;
+        switch (d) {
+        case 4: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 4>(SWK_C1_ARGS);
+        case 3: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 3>(SWK_C1_ARGS);
+        case 2: return launch_conv1x1_d<NBLK, 32, 2>(SWK_C1_ARGS);
+        default: return launch_conv1x1_d<NBLK, 32, 1>(SWK_C1_ARGS);
+        }
+    }
+    if (cin == 48) return launch_conv1x1_d<NBLK, 48, 1>(SWK_C1_ARGS);          // one pixel = one chunk (192 bytes)
+    return launch_conv1x1_d<NBLK, 16, 1>(SWK_C1_ARGS);
+}
+#undef SWK_C1_ARGS
 
 }  // namespace swk
 
@@ -123,7 +186,8 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off)
 {
-    if (!src || !weight || !bias || !dst || n < 1 || h < 1 || w < 1 || cin < 16 || (cin & 15) || cin > 1024 || cout < 1 || cout > 256 ||
+    if (!src || !weight || !bias || !dst || n < 1 || h < 1 || w < 1 || cin < 16 || (cin & 15) || cin > 1024 || cout < 4 || cout > 256 ||
+        (cout & 3) || (dC & 3) || (c_off & 3) || (((uintptr_t)dst) & 15) ||
         crop_y < 0 || crop_x < 0 || crop_y + h > sh || crop_x + w > sw || off_y < 0 || off_x < 0 || off_y + h > dH || off_x + w > dW ||
         c_off < 0 || c_off + cout > dC || (((uintptr_t)src) & 15))
         return SWK_ERR_ARG;
@@ -139,6 +203,14 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     case 8: return launch_conv1x1<8>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     default: return SWK_ERR_ARG;          // 5 and 7 blocks (129..160, 193..224 channels) do not occur in SqueezeNet-1.0
     }
+}
+
+// Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the 1x1
+// kernel (0 = deepest that fits, 1 = one chunk in flight).
+int32_t swk_set_cnn_tuning(int32_t knob, int32_t value)
+{
+    if (knob == 0 && (value == 0 || value == 1)) { swk::g_conv1x1_ring = value; return SWK_OK; }
+    return SWK_ERR_ARG;
 }
 
 }  // extern "C"

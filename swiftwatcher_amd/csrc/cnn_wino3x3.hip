@@ -1,0 +1,291 @@
+// The 3x3 expand convolutions of the wide Fire modules (fire4 .. fire9: 32 -> 128, 48 -> 192, 64 -> 256 channels, 94 of the
+// classifier's 125 M multiply-accumulates per segment) by Winograd's minimal filtering F(2x2, 3x3) on the f32 matrix cores:
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2 x 2 output tile, 4 x 4 input patch d, 3 x 3 filter g
+//
+// 16 multiplies per four outputs instead of 36: 2.25 x fewer MFMAs than the direct kernel (cnn_conv3x3.hip), which already
+// runs at three quarters of the f32 matrix peak.  Same interface and the same fused epilogue (bias + ReLU + placement behind
+// the expand1x1 channels); the filter transform U = G g G^T is made once per layer on the host
+// (swk_winograd_f2x2_3x3_weights, float64 then rounded).  Float32 results differ from the direct kernel by the usual
+// F(2x2, 3x3) rounding (a few 1e-7 relative to the output scale; tests/test_classifier.py).
+//
+// In the transformed domain the layer is 16 independent GEMMs, one per position p = (xi, nu) of the 4 x 4 patch:
+// M_p[tile][co] = sum_ci V_p[tile][ci] U_p[ci][co], and every output needs all 16 of them -- kept as 16 accumulators they
+// would be four times the outputs.  Instead the positions run one after the other, M_p is ONE accumulator, and after its
+// last k-step it is added with its coefficient A^T[i][xi] A^T[j][nu] in {0, +1, -1} into the four output accumulators Y_ij.
+//   * workgroup = CG x TGN waves: 32 TGN output tiles (2 x 2 pixels each, of any segments) x all output channels; wave
+//     (cg, tg) owns tile group tg (32 tiles) and 64 output channels: Y = 4 x 2 x 16 registers, M = 16 (one 32-channel
+//     column block at a time).
+//   * V_p = B^T d B restricted to position p is a signed sum of FOUR patch pixels.  The workgroup forms V_p for its tiles
+//     once (two (tile, 4-channel) items per thread: 4 float4 loads, 3 fmas per component), transposes it into LDS as
+//     [channel][tile] -- the matrix cores' pixel operand -- double buffered: position p + 1 is staged while p multiplies,
+//     one barrier per position.
+//   * U_p streams through LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass), one half position --
+//     the first or the second 32-channel column block of every wave -- at a time, double buffered: 16 to 32 KB per phase, laid
+//     out by the host exactly as it sits in LDS ([p][column half][16-channel chunk][k half][quad][channel][4]: an operand
+//     read is one ds_read_b128 per four k-steps, 512 contiguous bytes per half wave).  One barrier per phase = per 8 S MFMAs
+//     of a wave.  (A first version read U_p from L2 into registers one k-chunk ahead: the waves spent 43 % of their cycles
+//     waiting for those loads, SQ_WAIT_ANY / SQ_WAVE_CYCLES, and the matrix pipe was 43 % busy.)
+//   * MFMA roles as in cnn_conv1x1.hip: weights = A operand, tiles = B operand, so a register quad of an accumulator is four
+//     consecutive output channels of the lane's own tile: float4 stores.
+// Launched on the CALLER's stream (PyTorch's current stream).
+#include "swk_internal.h"
+
+#include <vector>
+
+namespace swk {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int NBLK, int TGN>
+__global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const float *__restrict__ src, int nseg, int t, int T,
+                                                                      const float *__restrict__ w2, const float *__restrict__ bias, int cout,
+                                                                      float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x,
+                                                                      int c_off)
+{
+    constexpr int CG = NBLK / 2, NT = 64 * CG * TGN, CIN = 8 * NBLK, S = CIN / 16, SLOTS = 32 * TGN, VP = SLOTS + 1, G4 = CIN / 4,
+                  NP = 32 * NBLK, CGR = 32 * CG, WPH = 16 * S * CGR, PPW = 2 * S / TGN;
+    static_assert(2 * NT == SLOTS * G4, "two staging items per thread");
+    static_assert((2 * S) % TGN == 0 && PPW * CG * TGN * 256 == WPH, "whole 1 KB pieces per wave");
+    extern __shared__ float lds[];                 // W[2][WPH] (filter operands of two phases), V[2][CIN][VP], the bias padded to NP
+    float *const W0 = lds, *const W1 = lds + WPH;
+    float *const V0 = lds + 2 * WPH, *const V1 = V0 + CIN * VP, *const lbias = V1 + CIN * VP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int cg = wave % CG, tg = wave / CG;
+    const int o = t - 2, TT = T * T;
+    const int64_t ntiles = (int64_t)nseg * TT, src_floats = (int64_t)nseg * t * t * CIN;
+    const int64_t ntasks = (ntiles + SLOTS - 1) / SLOTS;
+    if (tid < NP) lbias[tid] = tid < cout ? bias[tid] : 0.0f;
+
+    // ---- staging items of this thread: (tile slot, 4-channel group), channel group fastest (a wave reads whole pixels) ----
+    const int sg[2] = {tid % G4, (tid + NT) % G4}, sslot[2] = {tid / G4, (tid + NT) / G4};
+    int64_t sbase[2];
+    int slim[2];
+    auto stage_setup = [&](int64_t task) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int64_t m = task * SLOTS + sslot[k];
+            if (m >= ntiles) m = ntiles - 1;
+            const int64_t b = m / TT;
+            const int rem = (int)(m - b * TT), ty = rem / T, tx = rem - ty * T;
+            sbase[k] = ((b * t + 2 * ty) * t + 2 * tx) * (int64_t)CIN + 4 * sg[k];
+            const int64_t lim = src_floats - 4 - sbase[k];          // a patch may reach one row / column past an odd-sized tile
+            slim[k] = (int)(lim < (1 << 30) ? lim : (1 << 30));
+        }
+    };
+    float4 st[4];
+    // patch rows (columns) that position xi (nu) combines: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    //   xi = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3        -> first row {0,1,2,1}, second {2,2,1,3}, sign {-,+,-,-}
+    auto stage_issue = [&](int p, int k) {
+        const int xi = p >> 2, nu = p & 3;
+        const int ra0 = (0x1210 >> (4 * xi)) & 15, ra1 = (0x3122 >> (4 * xi)) & 15;
+        const int rb0 = (0x1210 >> (4 * nu)) & 15, rb1 = (0x3122 >> (4 * nu)) & 15;
+        const float *g = src + sbase[k];
+        const int lim = slim[k];
+        const int o00 = (ra0 * t + rb0) * CIN, o01 = (ra0 * t + rb1) * CIN, o10 = (ra1 * t + rb0) * CIN, o11 = (ra1 * t + rb1) * CIN;
+        st[0] = *(const float4 *)(g + (o00 < lim ? o00 : lim));
+        st[1] = *(const float4 *)(g + (o01 < lim ? o01 : lim));
+        st[2] = *(const float4 *)(g + (o10 < lim ? o10 : lim));
+        st[3] = *(const float4 *)(g + (o11 < lim ? o11 : lim));
+    };
+    auto stage_store = [&](int p, int k, float *Vn) {
+        const float sx = (p >> 2) == 1 ? 1.0f : -1.0f, sn = (p & 3) == 1 ? 1.0f : -1.0f;
+        float4 v;
+        v.x = __builtin_fmaf(__builtin_fmaf(st[3].x, sn, st[2].x), sx, __builtin_fmaf(st[1].x, sn, st[0].x));
+        v.y = __builtin_fmaf(__builtin_fmaf(st[3].y, sn, st[2].y), sx, __builtin_fmaf(st[1].y, sn, st[0].y));
+        v.z = __builtin_fmaf(__builtin_fmaf(st[3].z, sn, st[2].z), sx, __builtin_fmaf(st[1].z, sn, st[0].z));
+        v.w = __builtin_fmaf(__builtin_fmaf(st[3].w, sn, st[2].w), sx, __builtin_fmaf(st[1].w, sn, st[0].w));
+        float *q = Vn + 4 * sg[k] * VP + sslot[k];
+        q[0] = v.x; q[VP] = v.y; q[2 * VP] = v.z; q[3 * VP] = v.w;
+    };
+
+    // ---- filter operands of phase ph = 2 p + h: WPH floats, contiguous in w2, copied as they lie; PPW 1 KB pieces per wave ----
+    auto w_issue = [&](int ph, float *Wb) {
+        const float *g = w2 + (int64_t)ph * WPH + (wave * PPW) * 256 + lane * 4;
+        float *l = Wb + (wave * PPW) * 256;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + k * 256),
+                                             (__attribute__((address_space(3))) void *)(l + k * 256), 16, 0, 0);
+    };
+    // this lane's operand quads in a phase buffer: [chunk][k half][quad][CGR channels][4]
+    const int wlane = ((hh * 2) * CGR + cg * 32 + r) * 4;
+
+    int64_t task = blockIdx.x;
+    if (task < ntasks) {
+        stage_setup(task);
+        stage_issue(0, 0); stage_store(0, 0, V0);
+        stage_issue(0, 1); stage_store(0, 1, V0);
+        w_issue(0, W0);
+    }
+    __syncthreads();
+    for (; task < ntasks; task += gridDim.x) {
+        // ---- this lane's tile as the matrix cores see it: destination of its 2 x 2 outputs ----
+        const int64_t m = task * SLOTS + tg * 32 + r;
+        const bool valid = m < ntiles;
+        const int64_t mm = valid ? m : ntiles - 1;
+        const int64_t b = mm / TT;
+        const int rem = (int)(mm - b * TT), ty = rem / T, tx = rem - ty * T;
+        const int64_t ro = ((b * dH + off_y + 2 * ty) * dW + off_x + 2 * tx) * (int64_t)dC + c_off + 64 * cg + 4 * hh;
+        const bool vy1 = 2 * ty + 1 < o, vx1 = 2 * tx + 1 < o;
+        const bool more = task + gridDim.x < ntasks;
+        f16v Y[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = 0.0f;
+        for (int p = 0; p < 16; ++p) {
+            const float *Vc = (p & 1) ? V1 : V0;
+            float *Vn = (p & 1) ? V0 : V1;
+            const bool have_next = p < 15 || more;
+            const int pn = (p + 1) & 15;
+            if (p == 15 && more) stage_setup(task + gridDim.x);
+            const int xi = p >> 2, nu = p & 3;
+            // Y_ij += A^T[i][xi] A^T[j][nu] M_p,   A^T = [1 1 1 0; 0 1 -1 -1]
+            const float ax[2] = {xi < 3 ? 1.0f : 0.0f, xi == 0 ? 0.0f : xi == 1 ? 1.0f : -1.0f};
+            const float an[2] = {nu < 3 ? 1.0f : 0.0f, nu == 0 ? 0.0f : nu == 1 ? 1.0f : -1.0f};
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                // phase (p, nb): the next phase's filter operands and one item of the next position's patch pixels travel
+                // while this one multiplies
+                const float *Wc = nb ? W1 : W0;
+                if (nb == 0) w_issue(2 * p + 1, W1);
+                else if (have_next) w_issue(2 * pn, W0);
+                if (have_next) stage_issue(pn, nb);
+                f16v M;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) M[e] = 0.0f;
+#pragma unroll 1
+                for (int sub = 0; sub < S; ++sub) {
+                    const float *wq = Wc + sub * (16 * CGR) + wlane;
+                    const float4 w0 = *(const float4 *)wq, w1 = *(const float4 *)(wq + 4 * CGR);
+                    const float *vrow = Vc + (sub * 16 + 8 * hh) * VP + tg * 32 + r;
+                    float bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bv[i] = vrow[i * VP];
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, bv[0], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, bv[1], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, bv[2], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, bv[3], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, bv[4], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, bv[5], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, bv[6], M, 0, 0, 0);
+                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, bv[7], M, 0, 0, 0);
+                }
+                if (have_next) stage_store(pn, nb, Vn);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float c = ax[i] * an[j];
+                        if (c != 0.0f) {          // uniform
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = __builtin_fmaf(M[e], c, Y[i][j][nb][e]);
+                        }
+                    }
+                if (nb == 0) __syncthreads();          // the LDS-DMA pieces of every wave have landed, W0 is free
+            }
+            __syncthreads();
+        }
+        // ---- bias + ReLU + placement: register quads = four consecutive output channels of the lane's tile ----
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((i == 1 && !vy1) || (j == 1 && !vx1)) continue;
+                    float *q = dst + ro + ((int64_t)i * dW + j) * dC;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int c = 64 * cg + 32 * nb + 8 * g + 4 * hh;
+                            if (c < cout) {
+                                const float4 b4 = *(const float4 *)(lbias + c);
+                                float4 v;
+                                v.x = fmaxf(Y[i][j][nb][4 * g] + b4.x, 0.0f);
+                                v.y = fmaxf(Y[i][j][nb][4 * g + 1] + b4.y, 0.0f);
+                                v.z = fmaxf(Y[i][j][nb][4 * g + 2] + b4.z, 0.0f);
+                                v.w = fmaxf(Y[i][j][nb][4 * g + 3] + b4.w, 0.0f);
+                                *(float4 *)(q + 32 * nb + 8 * g) = v;
+                            }
+                        }
+                }
+        }
+    }
+}
+
+template <int NBLK, int TGN>
+static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const float *w2, const float *bias, int cout, float *dst, int dH,
+                          int dW, int dC, int off_y, int off_x, int c_off)
+{
+    constexpr int CIN = 8 * NBLK, SLOTS = 32 * TGN, NT = 32 * NBLK * TGN;
+    constexpr int S = CIN / 16, CGR = 16 * NBLK;
+    const size_t lds = (size_t)(2 * 16 * S * CGR + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, TGN>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    const int T = (t - 2 + 1) / 2;
+    const int64_t ntiles = (int64_t)n * T * T;
+    int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
+    if (blocks > 256) blocks = 256;                // one workgroup per CU (its waves hold ~250 registers), persistent over its tasks
+    hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, TGN>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW, dC,
+                       off_y, off_x, c_off);
+    return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+
+}  // namespace swk
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t cin, float *out)
+{
+    if (!weight || !out || cout < 1 || cin < 16 || (cin & 15)) return SWK_ERR_ARG;
+    // operand layout of k_wino3x3_relu_place: [p][h][chunk][k half][quad][cg * 32 + r][4] with output channel 64 cg + 32 h + r and
+    // input channel 16 chunk + 8 (k half) + 4 quad + j; output channels padded to a multiple of 64
+    const int CG = (cout + 63) / 64, CGR = 32 * CG, S = cin / 16;
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    for (int64_t i = 0, e = (int64_t)16 * cin * 2 * CGR; i < e; ++i) out[i] = 0.0f;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *g = weight + ((int64_t)co * cin + ci) * 9;
+            double tmp[4][3], U[4][4];
+            for (int a = 0; a < 4; ++a)
+                for (int c = 0; c < 3; ++c) tmp[a][c] = G[a][0] * g[c] + G[a][1] * g[3 + c] + G[a][2] * g[6 + c];
+            for (int a = 0; a < 4; ++a)
+                for (int c = 0; c < 4; ++c) U[a][c] = tmp[a][0] * G[c][0] + tmp[a][1] * G[c][1] + tmp[a][2] * G[c][2];
+            const int sub = ci >> 4, hh = (ci >> 3) & 1, q = (ci >> 2) & 1, j = ci & 3;
+            const int cg = co >> 6, h = (co >> 5) & 1, r = co & 31;
+            for (int p = 0; p < 16; ++p) {
+                int64_t idx = (int64_t)p * 2 + h;
+                idx = idx * S + sub;
+                idx = (idx * 2 + hh) * 2 + q;
+                idx = idx * CGR + cg * 32 + r;
+                out[idx * 4 + j] = (float)U[p >> 2][p & 3];
+            }
+        }
+    return SWK_OK;
+}
+
+int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight_w,
+                                                  const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC,
+                                                  int32_t off_y, int32_t off_x, int32_t c_off)
+{
+    if (!src || !weight_w || !bias || !dst || n < 1 || t < 3 || cout < 4 || (cout & 3) || (dC & 3) || (c_off & 3) || off_y < 0 || off_x < 0 ||
+        off_y + t - 2 > dH || off_x + t - 2 > dW || c_off < 0 || c_off + cout > dC || (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)weight_w) & 15))
+        return SWK_ERR_ARG;
+    using namespace swk;
+    hipStream_t s = (hipStream_t)stream;
+    // the squeeze ratio of SqueezeNet's Fire modules: 8 input channels per 32 output channels
+    if (cin == 32 && cout == 128) return launch_wino3x3<4, 4>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+    if (cin == 48 && cout == 192) return launch_wino3x3<6, 2>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+    if (cin == 64 && cout == 256) return launch_wino3x3<8, 2>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+    return SWK_ERR_ARG;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -168,7 +168,10 @@ class CroppedSqueezeNet10:
         # 1x1 convolutions by the library's own fused kernel (SWK_FUSED_1X1=0: through MIOpen + the placement kernel)
         self.fused_1x1 = os.environ.get("SWK_FUSED_1X1", "1") == "1"
         self.fused_3x3 = os.environ.get("SWK_FUSED_3X3", "1") == "1"
+        # wide 3x3 expands (fire4..9) by Winograd F(2x2, 3x3) (csrc/cnn_wino3x3.hip); SWK_WINOGRAD_3X3=0: the direct kernel
+        self.fused_wino = os.environ.get("SWK_WINOGRAD_3X3", "1") == "1"
         self._wt3 = {}
+        self._ww3 = {}
 
     def macs_per_segment(self):
         """Multiply-accumulates the convolutions of one forward execute per segment: (executed, useful).  "executed"
@@ -292,6 +295,21 @@ class CroppedSqueezeNet10:
 
         def conv3x3(src, j, conv, dest, off, c_off):
             src = nhwc(src)
+            cin, cout = conv.in_channels, conv.out_channels
+            if self.fused_wino and cout == 4 * cin and cin in (32, 48, 64):
+                ww = self._ww3.get(j)
+                if ww is None:       # G g G^T in the kernel's operand layout, once per layer (host code of the library)
+                    w = conv.weight.detach().to("cpu", torch.float32).contiguous()
+                    out = torch.empty(16 * cin * cout, dtype=torch.float32)
+                    if lib.swk_winograd_f2x2_3x3_weights(w.data_ptr(), cout, cin, out.data_ptr()):
+                        raise RuntimeError("swk_winograd_f2x2_3x3_weights failed")
+                    ww = self._ww3[j] = out.to(src.device)
+                rc = lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, src.data_ptr(), k, src.shape[2], cin, ww.data_ptr(),
+                                                                   conv.bias.data_ptr(), cout, dest.data_ptr(), dest.shape[2],
+                                                                   dest.shape[3], dest.shape[1], off, off, c_off)
+                if rc:
+                    raise RuntimeError("swk_nhwc_conv3x3_winograd_bias_relu_place failed (%d)" % rc)
+                return
             wt = self._wt3.get(j)
             if wt is None:       # [co][ci][3][3] -> [tap][ci][co], once per layer
                 wt = self._wt3[j] = conv.weight.detach().permute(2, 3, 1, 0).contiguous(memory_format=torch.contiguous_format)

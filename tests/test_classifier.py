@@ -311,7 +311,8 @@ def test_fused_conv1x1_kernel_against_torch():
         (5, 96, 16, 8, 0, 8, 12, 2, 16, 0), (3, 128, 32, 14, 0, 14, 16, 1, 32, 0), (7, 256, 48, 12, 0, 12, 14, 1, 48, 0),
         (4, 512, 64, 9, 0, 9, 13, 2, 64, 0), (6, 16, 64, 12, 1, 10, 10, 0, 128, 0), (3, 32, 128, 16, 1, 14, 17, 0, 256, 0),
         (2, 48, 192, 14, 1, 12, 12, 0, 384, 0), (3, 64, 256, 18, 1, 16, 19, 2, 512, 0), (1, 64, 96, 7, 2, 3, 5, 1, 160, 60),
-        (9, 16, 1, 5, 0, 5, 5, 0, 4, 3)]
+        (9, 16, 4, 5, 0, 5, 5, 0, 8, 4), (3, 80, 40, 6, 1, 5, 6, 1, 40, 0), (2, 384, 64, 14, 0, 14, 18, 2, 64, 0),
+        (2, 192, 24, 7, 0, 7, 7, 0, 24, 0), (37, 32, 128, 3, 0, 3, 3, 0, 128, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for n, cin, cout, sh, crop, size, dH, off, dC, c_off in cases:
         x = torch.randn((n, cin, sh, sh), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -337,6 +338,8 @@ def test_fused_conv1x1_kernel_against_torch():
     # bad arguments are refused, not launched
     assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 4, 4, 24, 0, 0, 4, 4, wgt.data_ptr(), bias.data_ptr(), 8,
                                                 dst.data_ptr(), 4, 4, 8, 0, 0, 0) != 0          # cin not a multiple of 16
+    assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 3, 3, 32, 0, 0, 3, 3, wgt.data_ptr(), bias.data_ptr(), 6,
+                                                dst.data_ptr(), 3, 3, 8, 0, 0, 0) != 0          # output channels not a multiple of 4
 
 
 @pytest.mark.gpu
@@ -376,3 +379,75 @@ def test_fused_conv3x3_kernel_against_torch():
         mask = torch.ones_like(dst, dtype=torch.bool)
         mask[:, c_off:c_off + cout, off:off + o, off:off + o] = False
         assert bool((dst[mask] == -7.0).all())
+
+
+def test_winograd_filter_transform_host():
+    """swk_winograd_f2x2_3x3_weights (host code): U = G g G^T of every filter, in the kernel's operand layout
+    [position][column half h][16-channel chunk][k half][quad][cg * 32 + r][4], output channel 64 cg + 32 h + r (padded to 64s),
+    input channel 16 chunk + 8 (k half) + 4 quad + j."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    cout, cin = 104, 32
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    CG = 2
+    out = np.full(16 * cin * 64 * CG, np.nan, np.float32)
+    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum("ak,oikl,bl->abio", G, w.astype(np.float64), G)              # [xi][nu][ci][co]
+    out = out.reshape(16, 2, cin // 16, 2, 2, CG, 32, 4)                         # p, h, chunk, k half, quad, cg, r, j
+    got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 64 * CG)      # -> [xi][nu][channel][64 cg + 32 h + r]
+    assert np.array_equal(got[..., :cout], U.astype(np.float32))
+    assert not got[..., cout:].any()
+    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, 24, out.ctypes.data_as(ctypes.c_void_p)) != 0
+
+
+@pytest.mark.gpu
+def test_winograd_conv3x3_kernel_against_torch():
+    """swk_nhwc_conv3x3_winograd_bias_relu_place (F(2x2, 3x3) on the f32 matrix cores) against torch.nn.functional.conv2d and
+    against the direct kernel, on the three Fire shapes it takes: even and odd output sizes (the odd one computes a half-used
+    last tile row / column whose patch reaches past the tile), batches that do not fill the last workgroup task, one segment.
+    Tolerance 1e-5 of the output scale (the transform adds a few roundings to the direct kernel's 2e-5 bound... measured 2e-6)."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(16)
+    cases = [  # n, cin, cout, t, dH, off, dC, c_off
+        (3, 32, 128, 16, 17, 1, 256, 128), (9, 32, 128, 12, 10, 0, 256, 128), (2, 48, 192, 14, 12, 0, 384, 192),
+        (3, 48, 192, 16, 14, 0, 384, 192), (2, 64, 256, 18, 19, 2, 512, 256), (5, 64, 256, 13, 11, 0, 512, 256),
+        (1, 64, 256, 3, 1, 0, 256, 0), (1, 32, 128, 5, 3, 0, 128, 0), (70, 64, 256, 7, 5, 0, 256, 0), (33, 48, 192, 4, 2, 0, 192, 0)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, cin, cout, t, dH, off, dC, c_off in cases:
+        x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wcpu = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).contiguous()
+        wgt = wcpu.to(dev)
+        bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+        ww = torch.empty(16 * cin * cout, dtype=torch.float32)
+        assert lib.swk_winograd_f2x2_3x3_weights(wcpu.data_ptr(), cout, cin, ww.data_ptr()) == 0
+        ww = ww.to(dev)
+        dst = torch.full((n, dC, dH, dH), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        exp = dst.clone()
+        direct = dst.clone()
+        y = torch.relu(torch.nn.functional.conv2d(x, wgt, bias))
+        o = t - 2
+        exp[:, c_off:c_off + cout, off:off + o, off:off + o] = y
+        torch.cuda.synchronize()
+        rc = lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), n, t, cin, ww.data_ptr(), bias.data_ptr(), cout,
+                                                           dst.data_ptr(), dH, dH, dC, off, off, c_off)
+        assert rc == 0, (rc, n, cin, cout, t)
+        wt = wgt.permute(2, 3, 1, 0).contiguous()
+        assert lib.swk_nhwc_conv3x3_bias_relu_place(stream, x.data_ptr(), n, t, cin, wt.data_ptr(), bias.data_ptr(), cout,
+                                                    direct.data_ptr(), dH, dH, dC, off, off, c_off) == 0
+        torch.cuda.synchronize()
+        scale = max(float(y.abs().max()), 1.0)
+        err = float((dst - exp).abs().max())
+        assert err <= 1e-5 * scale, (err, scale, n, cin, cout, t)
+        assert float((dst - direct).abs().max()) <= 1e-5 * scale
+        mask = torch.ones_like(dst, dtype=torch.bool)
+        mask[:, c_off:c_off + cout, off:off + o, off:off + o] = False
+        assert bool((dst[mask] == -7.0).all())
+    # shapes outside the Fire ratio are refused (the caller takes the direct kernel)
+    assert lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), 1, 4, 16, ww.data_ptr(), bias.data_ptr(), 64,
+                                                         dst.data_ptr(), 2, 2, 64, 0, 0, 0) != 0
