@@ -31,7 +31,7 @@
 // Launched on the CALLER's stream (PyTorch's current stream).
 #include "swk_internal.h"
 
-#include <vector>
+#include <type_traits>
 
 namespace swk {
 
@@ -57,10 +57,14 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
     const int64_t ntasks = (ntiles + SLOTS - 1) / SLOTS;
     if (tid < NP) lbias[tid] = tid < cout ? bias[tid] : 0.0f;
 
+    // Every vector instruction of this kernel is paid in matrix-pipe time: the exact-f32 MFMA and the f32 vector unit are
+    // one execution unit on gfx950 (profiles/r2_f32_pipe_probe.txt).  Hence 32-bit byte offsets against scalar bases
+    // (one v_min + one v_add per patch load), LDS-DMA pieces addressed by instruction offsets, zero coefficients skipped.
     // ---- staging items of this thread: (tile slot, 4-channel group), channel group fastest (a wave reads whole pixels) ----
     const int sg[2] = {tid % G4, (tid + NT) % G4}, sslot[2] = {tid / G4, (tid + NT) / G4};
-    int64_t sbase[2];
-    int slim[2];
+    unsigned sbase[2];          // byte offset of the item's patch origin in src
+    int slim[2];                // largest byte offset a patch load of the item may add (the last float4 of src)
+    const char *const srcb = (const char *)src;
     auto stage_setup = [&](int64_t task) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -68,8 +72,9 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
             if (m >= ntiles) m = ntiles - 1;
             const int64_t b = m / TT;
             const int rem = (int)(m - b * TT), ty = rem / T, tx = rem - ty * T;
-            sbase[k] = ((b * t + 2 * ty) * t + 2 * tx) * (int64_t)CIN + 4 * sg[k];
-            const int64_t lim = src_floats - 4 - sbase[k];          // a patch may reach one row / column past an odd-sized tile
+            const int64_t base = (((b * t + 2 * ty) * t + 2 * tx) * (int64_t)CIN + 4 * sg[k]) * 4;
+            const int64_t lim = src_floats * 4 - 16 - base;          // a patch may reach one row / column past an odd-sized tile
+            sbase[k] = (unsigned)base;
             slim[k] = (int)(lim < (1 << 30) ? lim : (1 << 30));
         }
     };
@@ -80,13 +85,13 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
         const int xi = p >> 2, nu = p & 3;
         const int ra0 = (0x1210 >> (4 * xi)) & 15, ra1 = (0x3122 >> (4 * xi)) & 15;
         const int rb0 = (0x1210 >> (4 * nu)) & 15, rb1 = (0x3122 >> (4 * nu)) & 15;
-        const float *g = src + sbase[k];
         const int lim = slim[k];
-        const int o00 = (ra0 * t + rb0) * CIN, o01 = (ra0 * t + rb1) * CIN, o10 = (ra1 * t + rb0) * CIN, o11 = (ra1 * t + rb1) * CIN;
-        st[0] = *(const float4 *)(g + (o00 < lim ? o00 : lim));
-        st[1] = *(const float4 *)(g + (o01 < lim ? o01 : lim));
-        st[2] = *(const float4 *)(g + (o10 < lim ? o10 : lim));
-        st[3] = *(const float4 *)(g + (o11 < lim ? o11 : lim));
+        const int o00 = (ra0 * t + rb0) * (CIN * 4), o01 = (ra0 * t + rb1) * (CIN * 4), o10 = (ra1 * t + rb0) * (CIN * 4),
+                  o11 = (ra1 * t + rb1) * (CIN * 4);
+        st[0] = *(const float4 *)(srcb + (sbase[k] + (unsigned)(o00 < lim ? o00 : lim)));
+        st[1] = *(const float4 *)(srcb + (sbase[k] + (unsigned)(o01 < lim ? o01 : lim)));
+        st[2] = *(const float4 *)(srcb + (sbase[k] + (unsigned)(o10 < lim ? o10 : lim)));
+        st[3] = *(const float4 *)(srcb + (sbase[k] + (unsigned)(o11 < lim ? o11 : lim)));
     };
     auto stage_store = [&](int p, int k, float *Vn) {
         const float sx = (p >> 2) == 1 ? 1.0f : -1.0f, sn = (p & 3) == 1 ? 1.0f : -1.0f;
@@ -99,15 +104,32 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
         q[0] = v.x; q[VP] = v.y; q[2 * VP] = v.z; q[3 * VP] = v.w;
     };
 
-    // ---- filter operands of phase ph = 2 p + h: WPH floats, contiguous in w2, copied as they lie; PPW 1 KB pieces per wave ----
+    // ---- filter operands of phase ph = 2 p + h: WPH floats, contiguous in w2, copied as they lie by LDS-DMA; PPW 1 KB pieces per
+    //      wave, addressed by the instruction offset (it advances the global and the LDS address alike).
+    // Written as an asm statement: through __builtin_amdgcn_global_load_lds the compiler treats the copy as an LDS store that
+    // every later ds_read may alias and waits for it (s_waitcnt vmcnt(0)) before the very next operand read -- the copy is then
+    // no longer asynchronous.  The waits are placed by hand instead (wait_copies(), before the barrier that ends a phase).
+    const unsigned wvoff = (unsigned)((wave * PPW) * 1024 + lane * 16);
+    const unsigned wpiece = __builtin_amdgcn_readfirstlane((unsigned)(wave * PPW) * 1024u);
     auto w_issue = [&](int ph, float *Wb) {
-        const float *g = w2 + (int64_t)ph * WPH + (wave * PPW) * 256 + lane * 4;
-        float *l = Wb + (wave * PPW) * 256;
-#pragma unroll
-        for (int k = 0; k < PPW; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + k * 256),
-                                             (__attribute__((address_space(3))) void *)(l + k * 256), 16, 0, 0);
+        const float *g = w2 + (int64_t)ph * WPH;          // uniform
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Wb) + wpiece;
+        unsigned keep;
+        if constexpr (PPW == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
+        else if constexpr (PPW == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "global_load_lds_dwordx4 %1, %3 offset:1024\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "global_load_lds_dwordx4 %1, %3 offset:1024\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, %3 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
     };
+    static_assert(PPW == 1 || PPW == 3 || PPW == 4, "LDS-DMA pieces per wave and phase");
+    auto wait_copies = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // this lane's operand quads in a phase buffer: [chunk][k half][quad][CGR channels][4]
     const int wlane = ((hh * 2) * CGR + cg * 32 + r) * 4;
 
@@ -118,6 +140,7 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
         stage_issue(0, 1); stage_store(0, 1, V0);
         w_issue(0, W0);
     }
+    wait_copies();
     __syncthreads();
     for (; task < ntasks; task += gridDim.x) {
         // ---- this lane's tile as the matrix cores see it: destination of its 2 x 2 outputs ----
@@ -138,58 +161,76 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = 0.0f;
+        // One phase = one 32-channel column block of one position: 8 S dependent MFMAs into M (two waves alternate on a SIMD:
+        // a dependent chain costs nothing, profiles/r2_f32_pipe_probe.txt), then Y_ij[nb] += c_ij M for the pairs the position feeds.
+        // The operands of k-chunk s + 1 are read from LDS while chunk s multiplies (two register sets; left alone the compiler
+        // reads each operand pair right before its two MFMAs and the wave sits out the LDS latency 4 S times per phase).
+        auto phase = [&](const float *Wc, const float *Vc) -> f16v {
+            const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            f16v M = zero;
+            const float *wq = Wc + wlane;
+            const float *vrow = Vc + (8 * hh) * VP + tg * 32 + r;
+            float4 w0[2], w1[2];
+            float bv[2][8];
+            w0[0] = *(const float4 *)wq;
+            w1[0] = *(const float4 *)(wq + 4 * CGR);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bv[0][i] = vrow[i * VP];
+#pragma unroll
+            for (int sub = 0; sub < S; ++sub) {
+                const int c = sub & 1, n = c ^ 1;
+                if (sub + 1 < S) {
+                    w0[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR));
+                    w1[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR) + 4 * CGR);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bv[n][i] = vrow[((sub + 1) * 16 + i) * VP];
+                }
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[c].x, bv[c][0], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[c].y, bv[c][1], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[c].z, bv[c][2], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[c].w, bv[c][3], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].x, bv[c][4], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].y, bv[c][5], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].z, bv[c][6], M, 0, 0, 0);
+                M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].w, bv[c][7], M, 0, 0, 0);
+                if (sub + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, 8, 0);
+            }
+            return M;
+        };
         for (int p = 0; p < 16; ++p) {
             const float *Vc = (p & 1) ? V1 : V0;
             float *Vn = (p & 1) ? V0 : V1;
-            const bool have_next = p < 15 || more;
             const int pn = (p + 1) & 15;
             if (p == 15 && more) stage_setup(task + gridDim.x);
-            const int xi = p >> 2, nu = p & 3;
             // Y_ij += A^T[i][xi] A^T[j][nu] M_p,   A^T = [1 1 1 0; 0 1 -1 -1]
+            const int xi = p >> 2, nu = p & 3;
             const float ax[2] = {xi < 3 ? 1.0f : 0.0f, xi == 0 ? 0.0f : xi == 1 ? 1.0f : -1.0f};
             const float an[2] = {nu < 3 ? 1.0f : 0.0f, nu == 0 ? 0.0f : nu == 1 ? 1.0f : -1.0f};
+            // (after a workgroup's last position the loads below fetch position 0 of the same tiles again, unused: conditional
+            //  loads would make the compiler wait for them where the branches join, i.e. at once)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                // phase (p, nb): the next phase's filter operands and one item of the next position's patch pixels travel
-                // while this one multiplies
-                const float *Wc = nb ? W1 : W0;
+                // ---- phase (p, nb): the next phase's filter operands and one item of the next position's patch pixels
+                //      travel while this one multiplies ----
                 if (nb == 0) w_issue(2 * p + 1, W1);
-                else if (have_next) w_issue(2 * pn, W0);
-                if (have_next) stage_issue(pn, nb);
-                f16v M;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) M[e] = 0.0f;
-#pragma unroll 1
-                for (int sub = 0; sub < S; ++sub) {
-                    const float *wq = Wc + sub * (16 * CGR) + wlane;
-                    const float4 w0 = *(const float4 *)wq, w1 = *(const float4 *)(wq + 4 * CGR);
-                    const float *vrow = Vc + (sub * 16 + 8 * hh) * VP + tg * 32 + r;
-                    float bv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) bv[i] = vrow[i * VP];
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, bv[0], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, bv[1], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, bv[2], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, bv[3], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, bv[4], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, bv[5], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, bv[6], M, 0, 0, 0);
-                    M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, bv[7], M, 0, 0, 0);
-                }
-                if (have_next) stage_store(pn, nb, Vn);
+                else w_issue(2 * pn, W0);
+                stage_issue(pn, nb);
+                const f16v M = phase(nb ? W1 : W0, Vc);
+                stage_store(pn, nb, Vn);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const float c = ax[i] * an[j];
-                        if (c != 0.0f) {          // uniform
+                        if (c != 0.0f) {          // uniform; 36 of the 64 (position, pair) combinations
 #pragma unroll
                             for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = __builtin_fmaf(M[e], c, Y[i][j][nb][e]);
                         }
                     }
-                if (nb == 0) __syncthreads();          // the LDS-DMA pieces of every wave have landed, W0 is free
+                wait_copies();
+                __syncthreads();          // the LDS-DMA pieces of every wave have landed, the other buffers are free
             }
-            __syncthreads();
         }
         // ---- bias + ReLU + placement: register quads = four consecutive output channels of the lane's tile ----
         if (valid) {
