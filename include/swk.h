@@ -225,7 +225,8 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 
 /* Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the
- * 1 x 1 kernel (0 = deepest that fits, 1 = one 16-channel chunk in flight). */
+ * 1 x 1 kernel (0 = deepest that fits, 1 = one chunk in flight); knob 1: the Winograd kernel's 64 -> 256 configuration (1 = one
+ * column block per wave, four waves per SIMD, the default; 0 = two blocks, two waves) -- set it before the filter transform. */
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value);
 
 /* conv3x3_bias_relu_place: the 3 x 3 expand convolution of a Fire module as a VALID convolution over the t x t squeeze tile

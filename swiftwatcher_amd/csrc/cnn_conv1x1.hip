@@ -155,6 +155,7 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
+extern int g_wino_nbw1;
 int g_conv1x1_ring = 0;          // 0: deepest ring that fits and divides the chunk count; 1: one chunk in flight (A/B knob)
 
 #define SWK_C1_ARGS s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
@@ -210,6 +211,7 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value)
 {
     if (knob == 0 && (value == 0 || value == 1)) { swk::g_conv1x1_ring = value; return SWK_OK; }
+    if (knob == 1 && (value == 0 || value == 1)) { swk::g_wino_nbw1 = value; return SWK_OK; }
     return SWK_ERR_ARG;
 }
 

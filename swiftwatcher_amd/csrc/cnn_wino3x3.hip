@@ -37,16 +37,37 @@ namespace swk {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-template <int NBLK, int TGN>
-__global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const float *__restrict__ src, int nseg, int t, int T,
+// Diagnostic build only (-DSWK_WINO_STAMP, tools/wino_stamp.py): s_memtime brackets around the parts of a phase, summed per wave
+// and stored to g_wino_stamp[wave][5] by lane 0.  Its fences forbid overlaps the real kernel has: read the shares, not the length.
+#ifdef SWK_WINO_STAMP
+int g_launch_error = 0;          // the diagnostic library is this file alone
+__device__ unsigned long long *g_wino_stamp;
+#define SWK_STAMP(k)                                                                                 \
+    do {                                                                                             \
+        unsigned long long t_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        stamp_sum[k] += t_ - stamp_last;                                                             \
+        stamp_last = t_;                                                                             \
+    } while (0)
+#else
+#define SWK_STAMP(k) do { } while (0)
+#endif
+
+template <int NBLK, int NBW, int TGN, int SPP, int WPS>
+__global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_place(const float *__restrict__ src, int nseg, int t, int T,
                                                                       const float *__restrict__ w2, const float *__restrict__ bias, int cout,
                                                                       float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x,
                                                                       int c_off)
 {
-    constexpr int CG = NBLK / 2, NT = 64 * CG * TGN, CIN = 8 * NBLK, S = CIN / 16, SLOTS = 32 * TGN, VP = SLOTS + 1, G4 = CIN / 4,
-                  NP = 32 * NBLK, CGR = 32 * CG, WPH = 16 * S * CGR, PPW = 2 * S / TGN;
-    static_assert(2 * NT == SLOTS * G4, "two staging items per thread");
-    static_assert((2 * S) % TGN == 0 && PPW * CG * TGN * 256 == WPH, "whole 1 KB pieces per wave");
+    // S k-chunks of 16 channels per position; a phase = SPP of them for one column block: PHS phases per (position, column block),
+    // PPOS per position
+    // a wave owns NBW column blocks of 32 output channels (WPS waves per SIMD fit: NBW = 2 -> 2, NBW = 1 -> 4)
+    constexpr int CG = NBLK / NBW, NW = CG * TGN, NT = 64 * NW, CIN = 8 * NBLK, S = CIN / 16, SLOTS = 32 * TGN, VP = SLOTS + 1, G4 = CIN / 4,
+                  NP = 32 * NBLK, CGR = 32 * CG, PHS = S / SPP, PPOS = NBW * PHS, WPH = 16 * SPP * CGR, PPW = WPH / (256 * NW);
+    static_assert(NBW * NT == SLOTS * G4, "NBW staging items per thread");
+    static_assert(S % SPP == 0 && PPW * NW * 256 == WPH, "whole 1 KB pieces per wave");
     extern __shared__ float lds[];                 // W[2][WPH] (filter operands of two phases), V[2][CIN][VP], the bias padded to NP
     float *const W0 = lds, *const W1 = lds + WPH;
     float *const V0 = lds + 2 * WPH, *const V1 = V0 + CIN * VP, *const lbias = V1 + CIN * VP;
@@ -55,19 +76,21 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
     const int o = t - 2, TT = T * T;
     const int64_t ntiles = (int64_t)nseg * TT, src_floats = (int64_t)nseg * t * t * CIN;
     const int64_t ntasks = (ntiles + SLOTS - 1) / SLOTS;
-    if (tid < NP) lbias[tid] = tid < cout ? bias[tid] : 0.0f;
+    for (int i = tid; i < NP; i += NT) lbias[i] = i < cout ? bias[i] : 0.0f;
 
     // Every vector instruction of this kernel is paid in matrix-pipe time: the exact-f32 MFMA and the f32 vector unit are
     // one execution unit on gfx950 (profiles/r2_f32_pipe_probe.txt).  Hence 32-bit byte offsets against scalar bases
     // (one v_min + one v_add per patch load), LDS-DMA pieces addressed by instruction offsets, zero coefficients skipped.
     // ---- staging items of this thread: (tile slot, 4-channel group), channel group fastest (a wave reads whole pixels) ----
-    const int sg[2] = {tid % G4, (tid + NT) % G4}, sslot[2] = {tid / G4, (tid + NT) / G4};
-    unsigned sbase[2];          // byte offset of the item's patch origin in src
-    int slim[2];                // largest byte offset a patch load of the item may add (the last float4 of src)
+    int sg[NBW], sslot[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) { sg[k] = (tid + k * NT) % G4; sslot[k] = (tid + k * NT) / G4; }
+    unsigned sbase[NBW];          // byte offset of the item's patch origin in src
+    int slim[NBW];              // largest byte offset a patch load of the item may add (the last float4 of src)
     const char *const srcb = (const char *)src;
     auto stage_setup = [&](int64_t task) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NBW; ++k) {
             int64_t m = task * SLOTS + sslot[k];
             if (m >= ntiles) m = ntiles - 1;
             const int64_t b = m / TT;
@@ -118,6 +141,10 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
         if constexpr (PPW == 1)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
+        else if constexpr (PPW == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "global_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
         else if constexpr (PPW == 3)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
                          "global_load_lds_dwordx4 %1, %3 offset:1024\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\ts_mov_b32 m0, %0"
@@ -128,16 +155,23 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
                          "global_load_lds_dwordx4 %1, %3 offset:3072\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(wvoff), "s"(l), "s"(g) : "memory");
     };
-    static_assert(PPW == 1 || PPW == 3 || PPW == 4, "LDS-DMA pieces per wave and phase");
+    static_assert(PPW >= 1 && PPW <= 4, "LDS-DMA pieces per wave and phase");
+    // the copies of a phase are issued BEFORE its patch loads: vmcnt(4) retires them and leaves the four patch loads in flight
     auto wait_copies = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto wait_copies_keep4 = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
     // this lane's operand quads in a phase buffer: [chunk][k half][quad][CGR channels][4]
     const int wlane = ((hh * 2) * CGR + cg * 32 + r) * 4;
+    constexpr int CB = 32 * NBW;          // output channels of a wave
 
+#ifdef SWK_WINO_STAMP
+    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     int64_t task = blockIdx.x;
     if (task < ntasks) {
         stage_setup(task);
-        stage_issue(0, 0); stage_store(0, 0, V0);
-        stage_issue(0, 1); stage_store(0, 1, V0);
+#pragma unroll
+        for (int k = 0; k < NBW; ++k) { stage_issue(0, k); stage_store(0, k, V0); }
         w_issue(0, W0);
     }
     wait_copies();
@@ -149,27 +183,26 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
         const int64_t mm = valid ? m : ntiles - 1;
         const int64_t b = mm / TT;
         const int rem = (int)(mm - b * TT), ty = rem / T, tx = rem - ty * T;
-        const int64_t ro = ((b * dH + off_y + 2 * ty) * dW + off_x + 2 * tx) * (int64_t)dC + c_off + 64 * cg + 4 * hh;
+        const int64_t ro = ((b * dH + off_y + 2 * ty) * dW + off_x + 2 * tx) * (int64_t)dC + c_off + CB * cg + 4 * hh;
         const bool vy1 = 2 * ty + 1 < o, vx1 = 2 * tx + 1 < o;
         const bool more = task + gridDim.x < ntasks;
-        f16v Y[2][2][2];
+        f16v Y[2][2][NBW];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = 0.0f;
-        // One phase = one 32-channel column block of one position: 8 S dependent MFMAs into M (two waves alternate on a SIMD:
-        // a dependent chain costs nothing, profiles/r2_f32_pipe_probe.txt), then Y_ij[nb] += c_ij M for the pairs the position feeds.
-        // The operands of k-chunk s + 1 are read from LDS while chunk s multiplies (two register sets; left alone the compiler
-        // reads each operand pair right before its two MFMAs and the wave sits out the LDS latency 4 S times per phase).
-        auto phase = [&](const float *Wc, const float *Vc) -> f16v {
-            const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            f16v M = zero;
+        // One phase = SPP k-chunks of one 32-channel column block of one position: 8 SPP dependent MFMAs into M (the waves
+        // that share a SIMD alternate: a dependent chain costs nothing, profiles/r2_f32_pipe_probe.txt).  After the last phase of
+        // a (position, column block): Y_ij[nb] += c_ij M for the pairs the position feeds.
+        // The operands of k-chunk s + 1 are read from LDS while chunk s multiplies (two register sets).  (Pinning the reads one MFMA
+        // pair ahead inside a chunk as well changed nothing: with two to four waves per SIMD the LDS latency is covered.)
+        auto phase = [&](const float *Wc, const float *Vc, int sub0, f16v M) -> f16v {
             const float *wq = Wc + wlane;
-            const float *vrow = Vc + (8 * hh) * VP + tg * 32 + r;
+            const float *vrow = Vc + (sub0 * 16 + 8 * hh) * VP + tg * 32 + r;
             float4 w0[2], w1[2];
             float bv[2][8];
             w0[0] = *(const float4 *)wq;
@@ -177,9 +210,9 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
 #pragma unroll
             for (int i = 0; i < 8; ++i) bv[0][i] = vrow[i * VP];
 #pragma unroll
-            for (int sub = 0; sub < S; ++sub) {
+            for (int sub = 0; sub < SPP; ++sub) {
                 const int c = sub & 1, n = c ^ 1;
-                if (sub + 1 < S) {
+                if (sub + 1 < SPP) {
                     w0[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR));
                     w1[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR) + 4 * CGR);
 #pragma unroll
@@ -193,8 +226,8 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
                 M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].y, bv[c][5], M, 0, 0, 0);
                 M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].z, bv[c][6], M, 0, 0, 0);
                 M = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[c].w, bv[c][7], M, 0, 0, 0);
-                if (sub + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, 8, 0);
+                if (sub + 1 < SPP) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 6, 0);
+                if (SPP > 1) __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, 8, 0);
             }
             return M;
         };
@@ -210,26 +243,44 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
             // (after a workgroup's last position the loads below fetch position 0 of the same tiles again, unused: conditional
             //  loads would make the compiler wait for them where the branches join, i.e. at once)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                // ---- phase (p, nb): the next phase's filter operands and one item of the next position's patch pixels
-                //      travel while this one multiplies ----
-                if (nb == 0) w_issue(2 * p + 1, W1);
-                else w_issue(2 * pn, W0);
-                stage_issue(pn, nb);
-                const f16v M = phase(nb ? W1 : W0, Vc);
-                stage_store(pn, nb, Vn);
+            for (int nb = 0; nb < NBW; ++nb) {
+                const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                f16v M = zero;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int h = 0; h < PHS; ++h) {
+                    // ---- phase q of the position: the next phase's filter operands travel while this one multiplies; the two items
+                    //      of the next position's patch pixels travel during its first and its second half ----
+                    const int q = nb * PHS + h;
+                    int gn = p * PPOS + q + 1;
+                    if (gn == 16 * PPOS) gn = 0;
+                    SWK_STAMP(5);
+                    const int par = (p * PPOS + q) & 1;          // phase buffers alternate over the whole sequence (PPOS may be odd)
+                    w_issue(gn, par ? W0 : W1);
+                    if (h == 0) stage_issue(pn, nb);          // item nb: issued in the first, stored in the last phase of block nb
+                    SWK_STAMP(0);
+                    M = phase(par ? W1 : W0, Vc, h * SPP, M);
+                    SWK_STAMP(1);
+                    if (h == PHS - 1) stage_store(pn, nb, Vn);
+                    if (h == PHS - 1) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float c = ax[i] * an[j];
-                        if (c != 0.0f) {          // uniform; 36 of the 64 (position, pair) combinations
+                        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = __builtin_fmaf(M[e], c, Y[i][j][nb][e]);
-                        }
+                            for (int j = 0; j < 2; ++j) {
+                                const float c = ax[i] * an[j];
+                                if (c != 0.0f) {          // uniform; 36 of the 64 (position, pair) combinations
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) Y[i][j][nb][e] = __builtin_fmaf(M[e], c, Y[i][j][nb][e]);
+                                }
+                            }
                     }
-                wait_copies();
-                __syncthreads();          // the LDS-DMA pieces of every wave have landed, the other buffers are free
+                    SWK_STAMP(2);
+                    // patch loads issued in this phase and stored in a later one stay in flight across the barrier
+                    if (h == 0 && PHS > 1) wait_copies_keep4();
+                    else wait_copies();
+                    SWK_STAMP(3);
+                    __syncthreads();          // the LDS-DMA pieces of every wave have landed, the other buffers are free
+                    SWK_STAMP(4);
+                }
             }
         }
         // ---- bias + ReLU + placement: register quads = four consecutive output channels of the lane's tile ----
@@ -241,10 +292,10 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
                     if ((i == 1 && !vy1) || (j == 1 && !vx1)) continue;
                     float *q = dst + ro + ((int64_t)i * dW + j) * dC;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int c = 64 * cg + 32 * nb + 8 * g + 4 * hh;
+                            const int c = CB * cg + 32 * nb + 8 * g + 4 * hh;
                             if (c < cout) {
                                 const float4 b4 = *(const float4 *)(lbias + c);
                                 float4 v;
@@ -258,23 +309,37 @@ __global__ __launch_bounds__(32 * NBLK * TGN) void k_wino3x3_relu_place(const fl
                 }
         }
     }
+#ifdef SWK_WINO_STAMP
+    SWK_STAMP(5);
+    if (lane == 0 && g_wino_stamp) {
+        unsigned long long *o = g_wino_stamp + ((int64_t)blockIdx.x * NW + wave) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = stamp_sum[i];
+    }
+#endif
 }
 
-template <int NBLK, int TGN>
+int g_wino_nbw1 = 1;          // A/B knob (swk_set_cnn_tuning 1): one column block per wave (three or four waves per SIMD) or two
+// column blocks per wave of the configuration a shape runs on (the filter layout depends on it)
+static int wino_nbw(int, int) { return g_wino_nbw1 ? 1 : 2; }
+
+template <int NBLK, int NBW, int TGN, int SPP, int WPS>
 static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const float *w2, const float *bias, int cout, float *dst, int dH,
                           int dW, int dC, int off_y, int off_x, int c_off)
 {
-    constexpr int CIN = 8 * NBLK, SLOTS = 32 * TGN, NT = 32 * NBLK * TGN;
-    constexpr int S = CIN / 16, CGR = 16 * NBLK;
-    const size_t lds = (size_t)(2 * 16 * S * CGR + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
+    constexpr int CIN = 8 * NBLK, SLOTS = 32 * TGN, NT = 64 * (NBLK / NBW) * TGN, CGR = 32 * (NBLK / NBW);
+    const size_t lds = (size_t)(2 * 16 * SPP * CGR + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, TGN>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if ((int64_t)n * t * t * CIN * 4 >= ((int64_t)1 << 32)) return SWK_ERR_CAPACITY;          // 32-bit byte offsets into src
     const int T = (t - 2 + 1) / 2;
     const int64_t ntiles = (int64_t)n * T * T;
     int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
-    if (blocks > 256) blocks = 256;                // one workgroup per CU (its waves hold ~250 registers), persistent over its tasks
-    hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, TGN>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW, dC,
-                       off_y, off_x, c_off);
+    // persistent workgroups of three or four waves (~230 registers): two waves per SIMD = two workgroups per CU, whose barriers
+    // are independent -- one's phase change (drain, update, barrier, first operand reads) is covered by the other's MFMAs
+    const int64_t cap = 256 * ((4 * WPS) / (NT / 64));
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW,
+                       dC, off_y, off_x, c_off);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
@@ -283,14 +348,22 @@ static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const f
 #pragma GCC visibility push(default)
 extern "C" {
 
+#ifdef SWK_WINO_STAMP
+int32_t swk_wino_stamp_buffer(unsigned long long *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(swk::g_wino_stamp), &buf, sizeof(buf)) == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+#endif
+
 int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t cin, float *out)
 {
     if (!weight || !out || cout < 1 || cin < 16 || (cin & 15)) return SWK_ERR_ARG;
-    // operand layout of k_wino3x3_relu_place: [p][h][chunk][k half][quad][cg * 32 + r][4] with output channel 64 cg + 32 h + r and
-    // input channel 16 chunk + 8 (k half) + 4 quad + j; output channels padded to a multiple of 64
-    const int CG = (cout + 63) / 64, CGR = 32 * CG, S = cin / 16;
+    // operand layout of k_wino3x3_relu_place: [p][h][chunk][k half][quad][cg * 32 + r][4] with output channel 32 NBW cg + 32 h + r
+    // (NBW = column blocks per wave of the kernel configuration this shape runs on, h < NBW) and input channel
+    // 16 chunk + 8 (k half) + 4 quad + j; output channels padded to a multiple of 32 NBW
+    const int NBW = swk::wino_nbw(cin, cout), CB = 32 * NBW, CG = (cout + CB - 1) / CB, CGR = 32 * CG, S = cin / 16;
     static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-    for (int64_t i = 0, e = (int64_t)16 * cin * 2 * CGR; i < e; ++i) out[i] = 0.0f;
+    for (int64_t i = 0, e = (int64_t)16 * cin * NBW * CGR; i < e; ++i) out[i] = 0.0f;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
             const float *g = weight + ((int64_t)co * cin + ci) * 9;
@@ -300,9 +373,9 @@ int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t
             for (int a = 0; a < 4; ++a)
                 for (int c = 0; c < 4; ++c) U[a][c] = tmp[a][0] * G[c][0] + tmp[a][1] * G[c][1] + tmp[a][2] * G[c][2];
             const int sub = ci >> 4, hh = (ci >> 3) & 1, q = (ci >> 2) & 1, j = ci & 3;
-            const int cg = co >> 6, h = (co >> 5) & 1, r = co & 31;
+            const int cg = co / CB, h = (co % CB) >> 5, r = co & 31;
             for (int p = 0; p < 16; ++p) {
-                int64_t idx = (int64_t)p * 2 + h;
+                int64_t idx = (int64_t)p * NBW + h;
                 idx = idx * S + sub;
                 idx = (idx * 2 + hh) * 2 + q;
                 idx = idx * CGR + cg * 32 + r;
@@ -322,9 +395,12 @@ int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src
     using namespace swk;
     hipStream_t s = (hipStream_t)stream;
     // the squeeze ratio of SqueezeNet's Fire modules: 8 input channels per 32 output channels
-    if (cin == 32 && cout == 128) return launch_wino3x3<4, 4>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
-    if (cin == 48 && cout == 192) return launch_wino3x3<6, 2>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
-    if (cin == 64 && cout == 256) return launch_wino3x3<8, 2>(s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+#define SWK_W3_ARGS s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
+    const bool one = wino_nbw(cin, cout) == 1;
+    if (cin == 32 && cout == 128) return one ? launch_wino3x3<4, 1, 1, 1, 4>(SWK_W3_ARGS) : launch_wino3x3<4, 2, 2, 2, 2>(SWK_W3_ARGS);
+    if (cin == 48 && cout == 192) return one ? launch_wino3x3<6, 1, 2, 1, 3>(SWK_W3_ARGS) : launch_wino3x3<6, 2, 2, 3, 2>(SWK_W3_ARGS);
+    if (cin == 64 && cout == 256) return one ? launch_wino3x3<8, 1, 1, 1, 4>(SWK_W3_ARGS) : launch_wino3x3<8, 2, 1, 2, 2>(SWK_W3_ARGS);
+#undef SWK_W3_ARGS
     return SWK_ERR_ARG;
 }
 

@@ -383,23 +383,29 @@ def test_fused_conv3x3_kernel_against_torch():
 
 def test_winograd_filter_transform_host():
     """swk_winograd_f2x2_3x3_weights (host code): U = G g G^T of every filter, in the kernel's operand layout
-    [position][column half h][16-channel chunk][k half][quad][cg * 32 + r][4], output channel 64 cg + 32 h + r (padded to 64s),
-    input channel 16 chunk + 8 (k half) + 4 quad + j."""
+    [position][column block h of a wave][16-channel chunk][k half][quad][cg * 32 + r][4], output channel 32 NBW cg + 32 h + r
+    (padded to a multiple of 32 NBW), input channel 16 chunk + 8 (k half) + 4 quad + j; NBW = column blocks per wave of the kernel
+    configuration (1 by default, 2 with the measurement knob)."""
     import ctypes
     from swiftwatcher_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(3)
     cout, cin = 104, 32
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
-    CG = 2
-    out = np.full(16 * cin * 64 * CG, np.nan, np.float32)
-    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum("ak,oikl,bl->abio", G, w.astype(np.float64), G)              # [xi][nu][ci][co]
-    out = out.reshape(16, 2, cin // 16, 2, 2, CG, 32, 4)                         # p, h, chunk, k half, quad, cg, r, j
-    got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 64 * CG)      # -> [xi][nu][channel][64 cg + 32 h + r]
-    assert np.array_equal(got[..., :cout], U.astype(np.float32))
-    assert not got[..., cout:].any()
+    try:
+        for nbw in (2, 1):
+            assert lib.swk_set_cnn_tuning(1, 1 if nbw == 1 else 0) == 0
+            CG = -(-cout // (32 * nbw))
+            out = np.full(16 * cin * nbw * 32 * CG, np.nan, np.float32)
+            assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
+            out = out.reshape(16, nbw, cin // 16, 2, 2, CG, 32, 4)                   # p, h, chunk, k half, quad, cg, r, j
+            got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 32 * nbw * CG)      # -> [xi][nu][channel][32 NBW cg + 32 h + r]
+            assert np.array_equal(got[..., :cout], U.astype(np.float32))
+            assert not got[..., cout:].any()
+    finally:
+        assert lib.swk_set_cnn_tuning(1, 1) == 0
     assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, 24, out.ctypes.data_as(ctypes.c_void_p)) != 0
 
 
@@ -419,7 +425,8 @@ def test_winograd_conv3x3_kernel_against_torch():
         (3, 48, 192, 16, 14, 0, 384, 192), (2, 64, 256, 18, 19, 2, 512, 256), (5, 64, 256, 13, 11, 0, 512, 256),
         (1, 64, 256, 3, 1, 0, 256, 0), (1, 32, 128, 5, 3, 0, 128, 0), (70, 64, 256, 7, 5, 0, 256, 0), (33, 48, 192, 4, 2, 0, 192, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    for n, cin, cout, t, dH, off, dC, c_off in cases:
+    for knob, (n, cin, cout, t, dH, off, dC, c_off) in [(1, c) for c in cases] + [(0, c) for c in cases[:6]]:
+        assert lib.swk_set_cnn_tuning(1, knob) == 0          # one (default) or two column blocks per wave: different kernels and layouts
         x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         wcpu = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).contiguous()
         wgt = wcpu.to(dev)
@@ -448,6 +455,7 @@ def test_winograd_conv3x3_kernel_against_torch():
         mask = torch.ones_like(dst, dtype=torch.bool)
         mask[:, c_off:c_off + cout, off:off + o, off:off + o] = False
         assert bool((dst[mask] == -7.0).all())
+    assert lib.swk_set_cnn_tuning(1, 1) == 0
     # shapes outside the Fire ratio are refused (the caller takes the direct kernel)
     assert lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), 1, 4, 16, ww.data_ptr(), bias.data_ptr(), 64,
                                                          dst.data_ptr(), 2, 2, 64, 0, 0, 0) != 0

@@ -2,7 +2,7 @@
 swk_nhwc_* call of CroppedSqueezeNet10._forward_hip_glue is bracketed by events on PyTorch's stream.  Prints one row per
 call with its multiply-accumulate rate and the activation bytes it has to move, and a JSON summary as the last line.
 
-    python3 tools/bench_convs.py [batch] [reps] [1x1 ring knob]
+    python3 tools/bench_convs.py [batch] [reps] [1x1 ring knob] [Winograd one-block-waves knob]
 """
 import json
 import os
@@ -68,6 +68,8 @@ def main():
     ring = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     if _lib.load().swk_set_cnn_tuning(0, ring):
         raise SystemExit("swk_set_cnn_tuning refused %d" % ring)
+    if len(sys.argv) > 4 and _lib.load().swk_set_cnn_tuning(1, int(sys.argv[4])):
+        raise SystemExit("swk_set_cnn_tuning(1) refused")
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "w.pt")
         torch.save(ref.random_state_dict(0), path)
