@@ -14,20 +14,27 @@
 // would be four times the outputs.  Instead the positions run one after the other, M_p is ONE accumulator, and after its
 // last k-step it is added with its coefficient A^T[i][xi] A^T[j][nu] in {0, +1, -1} into the four output accumulators Y_ij.
 //   * workgroup = CG x TGN waves: 32 TGN output tiles (2 x 2 pixels each, of any segments) x all output channels; wave
-//     (cg, tg) owns tile group tg (32 tiles) and 64 output channels: Y = 4 x 2 x 16 registers, M = 16 (one 32-channel
-//     column block at a time).
+//     (cg, tg) owns tile group tg (32 tiles) and NBW column blocks of 32 output channels: Y = 4 x NBW x 16 registers, M = 16.
+//     NBW = 1 is the default: 128 registers, four waves per SIMD (8-wave workgroups for 64 -> 256, 4-wave ones for 32 -> 128;
+//     48 -> 192 has six column blocks and runs as ONE 12-wave workgroup per CU, three waves on every SIMD -- two 6-wave
+//     workgroups do not become co-resident and leave two SIMDs half empty).  NBW = 2 (226 registers, two waves per SIMD)
+//     is kept behind swk_set_cnn_tuning(1, 0): 6 % slower on 64 -> 256, 15 % on 32 -> 128.
 //   * V_p = B^T d B restricted to position p is a signed sum of FOUR patch pixels.  The workgroup forms V_p for its tiles
-//     once (two (tile, 4-channel) items per thread: 4 float4 loads, 3 fmas per component), transposes it into LDS as
-//     [channel][tile] -- the matrix cores' pixel operand -- double buffered: position p + 1 is staged while p multiplies,
-//     one barrier per position.
-//   * U_p streams through LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass), one half position --
-//     the first or the second 32-channel column block of every wave -- at a time, double buffered: 16 to 32 KB per phase, laid
-//     out by the host exactly as it sits in LDS ([p][column half][16-channel chunk][k half][quad][channel][4]: an operand
-//     read is one ds_read_b128 per four k-steps, 512 contiguous bytes per half wave).  One barrier per phase = per 8 S MFMAs
-//     of a wave.  (A first version read U_p from L2 into registers one k-chunk ahead: the waves spent 43 % of their cycles
-//     waiting for those loads, SQ_WAIT_ANY / SQ_WAVE_CYCLES, and the matrix pipe was 43 % busy.)
+//     once (NBW (tile, 4-channel) items per thread: 4 float4 loads, 3 fmas per component), transposes it into LDS as
+//     [channel][tile] -- the matrix cores' pixel operand -- double buffered: position p + 1 is staged while p multiplies
+//     (loads issued in the first, transform and LDS store in the last phase of the position).
+//   * U_p streams through LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass) in phases of SPP k-chunks
+//     (16 channels each) of one column block of every wave, double buffered: 8 to 18 KB per phase, laid out by the host
+//     exactly as it sits in LDS ([p][column block][chunk][k half][quad][channel][4]: an operand read is one ds_read_b128 per
+//     four k-steps, 512 contiguous bytes per half wave).  One barrier per phase = per 8 SPP MFMAs of a wave.
+//     (A first version read U_p from L2 into registers one k-chunk ahead: the waves spent 43 % of their cycles waiting for
+//     those loads, SQ_WAIT_ANY / SQ_WAVE_CYCLES, and the matrix pipe was 43 % busy.)
 //   * MFMA roles as in cnn_conv1x1.hip: weights = A operand, tiles = B operand, so a register quad of an accumulator is four
 //     consecutive output channels of the lane's own tile: float4 stores.
+// Where it stands (MI355X, batch 4096, tools/bench_convs.py): 64 -> 256 on 16 x 16 outputs 1.36 ms against 2.63 ms for the
+// direct kernel; the matrix pipe is 65 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the f32 vector instructions that share it
+// (profiles/r2_f32_pipe_probe.txt) another 10 %; s_memtime brackets (tools/wino_stamp.py) put a wave's remaining time into
+// the barrier (19 %) and the phase prologue / epilogue; skipping the global loads altogether gains 9 %.
 // Launched on the CALLER's stream (PyTorch's current stream).
 #include "swk_internal.h"
 

@@ -174,22 +174,30 @@ class CroppedSqueezeNet10:
         self._ww3 = {}
 
     def macs_per_segment(self):
-        """Multiply-accumulates the convolutions of one forward execute per segment: (executed, useful).  "executed"
-        counts every output the kernels produce (the 1x1 expands run over the whole squeeze tile, ring included);
-        "useful" only the outputs the next layer reads.  The full 224 x 224 network does 0.7326 G."""
+        """Multiply-accumulates of one forward per segment: (executed, useful).  "useful" prices every convolution output the next
+        layer reads as a direct convolution (the figure to compare networks and hardware with); "executed" is what the kernels
+        really multiply: the Winograd F(2x2, 3x3) kernel does 16 instead of 36 per 2 x 2 outputs (tiles padded to even sizes), the
+        MIOpen path (fused kernels off) runs the 1x1 expands over the whole squeeze tile.  The full 224 x 224 network does 0.7326 G."""
         m = self.model
         c1 = m.features[0]
         side = (self.IN_HI - self.IN_LO + 1 - 7) // 2 + 1
         executed = useful = side * side * c1.out_channels * c1.in_channels * 49
         last_n = None
+        on_gpu = self.ring_sum.is_cuda and self.memory_format == torch.channels_last
         for kind, layer, tile, off, n, pad, crop in self.plan:
             if kind != "fire":
                 continue
             t = tile.shape[2] + pad[0] + pad[1]
             sq, e1, e3 = layer.squeeze, layer.expand1x1, layer.expand3x3
             executed += n * n * sq.out_channels * sq.in_channels
-            e1_side = crop[1] if getattr(self, "fused_1x1", False) else t      # the fused kernel only computes the rows that are used
-            executed += e1_side * e1_side * e1.out_channels * e1.in_channels + (t - 2) ** 2 * e3.out_channels * e3.in_channels * 9
+            e1_side = crop[1] if (on_gpu and self.fused_1x1) else t      # the fused kernel only computes the rows that are used
+            executed += e1_side * e1_side * e1.out_channels * e1.in_channels
+            wino = on_gpu and self.fused_3x3 and self.fused_wino and e3.out_channels == 4 * e3.in_channels and e3.in_channels in (32, 48, 64)
+            if wino:
+                tiles = ((t - 2 + 1) // 2) ** 2
+                executed += tiles * 16 * e3.out_channels * e3.in_channels
+            else:
+                executed += (t - 2) ** 2 * e3.out_channels * e3.in_channels * 9
             useful += n * n * sq.out_channels * sq.in_channels
             useful += crop[1] ** 2 * (e1.out_channels * e1.in_channels + e3.out_channels * e3.in_channels * 9)
             last_n = crop[1]
