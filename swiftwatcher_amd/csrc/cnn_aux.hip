@@ -1,7 +1,7 @@
-// Glue kernels of the receptive-field cropped classifier (swiftwatcher_amd/segment_classification.py): the
-// convolutions stay with MIOpen (PyTorch-ROCm), but between them PyTorch needs three passes over every activation
-// (bias add, ReLU, copy into the next layer's tile) and its NHWC max-pool kernel runs far below the memory rate.
-// Both are plain streaming jobs; they are launched on the CALLER's stream (PyTorch's current stream).
+// Glue kernels of the receptive-field cropped classifier (swiftwatcher_amd/segment_classification.py): what is left between
+// the convolution kernels (cnn_conv1x1.hip, cnn_conv3x3.hip, cnn_wino3x3.hip, which carry bias, ReLU and placement
+// themselves) -- bias + ReLU + crop behind conv1 (MIOpen), and the three max-pools (PyTorch's NHWC max-pool kernel runs far
+// below the memory rate).  Plain streaming jobs, launched on the CALLER's stream (PyTorch's current stream).
 // Layout: channels-last dense float32, tensor (n, c, h, w) = memory [n][h][w][c].
 #include "swk_internal.h"
 

@@ -30,18 +30,23 @@ namespace swk {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-template <int NBLK, int KC, int D>
-__global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restrict__ src, int64_t rows, int sh, int sw, int cin, int crop_y,
+// CS = column splits: CS waves share a row tile, each computing NBLK / CS of its 32-channel column blocks (they load the same
+// activations; the accumulators of a wave shrink to 16 NBLK / CS registers).  NWV = waves per workgroup: 16 (one workgroup per
+// CU whatever its weight matrix takes of the LDS, four waves per SIMD at <= 128 registers) or 8 (two per SIMD).
+template <int NBLK, int KC, int D, int CS, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__restrict__ src, int64_t rows, int sh, int sw, int cin, int crop_y,
                                                             int crop_x, int h, int w, const float *__restrict__ wgt, const float *__restrict__ bias,
                                                             int cout, float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
-    constexpr int NP = 32 * NBLK, PITCH = NP + 1, KH = KC / 2, NV = KH / 4;
+    constexpr int NP = 32 * NBLK, PITCH = NP + 1, KH = KC / 2, NV = KH / 4, NB = NBLK / CS, NT = 64 * NWV, SLOTS = NWV / CS;
+    static_assert(NBLK % CS == 0 && NWV % CS == 0, "column splits");
     extern __shared__ float lds[];                 // weights [cin][PITCH], then the bias padded to NP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     float *lbias = lds + ((cin * PITCH + 3) & ~3);
     const int hw = h * w;
-    const int64_t ntiles = (rows + 31) >> 5, stride = (int64_t)gridDim.x * 8;
-    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    const int cs = wave % CS;          // this wave's column blocks: cs * NB .. cs * NB + NB - 1
+    const int64_t ntiles = (rows + 31) >> 5, stride = (int64_t)gridDim.x * SLOTS;
+    int64_t tile = (int64_t)blockIdx.x * SLOTS + wave / CS;
 
     // source pointer and destination offset of this lane's pixel in a row tile (rows past the end repeat the last one)
     auto locate = [&](int64_t t, int64_t &ro) -> const float * {
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
         const int64_t b = mm / hw;
         const int rem = (int)(mm - b * hw);
         const int y = rem / w, x = rem - y * w;
-        ro = valid ? ((b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off : -1;
+        ro = valid ? ((b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off + 32 * NB * cs : -1;
         return src + ((b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + KH * hh;
     };
     float4 a[D][NV];
@@ -65,19 +70,19 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
             for (int v = 0; v < NV; ++v) a[d][v] = *(const float4 *)(p + KC * d + 4 * v);
     }
     // ---- weights, transposed: coalesced along ci in W[co][ci], conflict-free in LDS ----
-    for (int i = tid; i < cin * NP; i += 512) {
+    for (int i = tid; i < cin * NP; i += NT) {
         const int co = i / cin, ci = i - co * cin;
         lds[ci * PITCH + co] = co < cout ? wgt[(int64_t)co * cin + ci] : 0.0f;
     }
-    if (tid < NP) lbias[tid] = tid < cout ? bias[tid] : 0.0f;
+    for (int i = tid; i < NP; i += NT) lbias[i] = i < cout ? bias[i] : 0.0f;
     __syncthreads();
 
     for (; tile < ntiles; tile += stride) {
         const bool more = tile + stride < ntiles;
         if (more) pn = locate(tile + stride, ro_next);
-        f16v acc[NBLK];
+        f16v acc[NB];
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
         for (int kb = 0; kb < cin; kb += KC * D) {
@@ -97,20 +102,20 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
                 }
                 // weight operands of step i + 1 are read from LDS while step i multiplies (two register sets, scheduling
                 // fences: left alone the compiler reads each operand right before its MFMA and the wave waits out the LDS latency)
-                const float *wrow = lds + (k0 + KH * hh) * PITCH + r;
-                float bw[2][NBLK];
+                const float *wrow = lds + (k0 + KH * hh) * PITCH + 32 * NB * cs + r;
+                float bw[2][NB];
 #pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) bw[0][nb] = wrow[32 * nb];
+                for (int nb = 0; nb < NB; ++nb) bw[0][nb] = wrow[32 * nb];
 #pragma unroll
                 for (int i = 0; i < KH; ++i) {
                     if (i < KH - 1) {
 #pragma unroll
-                        for (int nb = 0; nb < NBLK; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
+                        for (int nb = 0; nb < NB; ++nb) bw[(i + 1) & 1][nb] = wrow[(i + 1) * PITCH + 32 * nb];
                     }
 #pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[i & 1][nb], av[i], acc[nb], 0, 0, 0);
-                    if (i < KH - 1) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NBLK, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NBLK, 0);
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[i & 1][nb], av[i], acc[nb], 0, 0, 0);
+                    if (i < KH - 1) __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, NB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008 /* MFMA */, NB, 0);
                 }
             }
         }
@@ -118,12 +123,12 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
         if (ro >= 0) {
             float *o = dst + ro + 4 * hh;
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int c = nb * 32 + 8 * g;
-                    if (c + 4 * hh < cout) {
-                        const float4 b4 = *(const float4 *)(lbias + c + 4 * hh);
+                    const int c = nb * 32 + 8 * g;          // relative to the wave's first column block
+                    if (32 * NB * cs + c + 4 * hh < cout) {
+                        const float4 b4 = *(const float4 *)(lbias + 32 * NB * cs + c + 4 * hh);
                         float4 v;
                         v.x = fmaxf(acc[nb][4 * g] + b4.x, 0.0f);
                         v.y = fmaxf(acc[nb][4 * g + 1] + b4.y, 0.0f);
@@ -138,43 +143,52 @@ __global__ __launch_bounds__(512) void k_conv1x1_relu_place(const float *__restr
     }
 }
 
-template <int NBLK, int KC, int D>
+template <int NBLK, int KC, int D, int CS, int NWV>
 static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
                             const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
     const size_t lds = (size_t)(((cin * (32 * NBLK + 1) + 3) & ~3) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
     if (lds > 160 * 1024 - 256) return SWK_ERR_CAPACITY;
+    constexpr int SLOTS = NWV / CS;
     const int64_t ntiles = (rows + 31) / 32;
-    int64_t blocks = (ntiles + 7) / 8;
-    const int64_t cap = lds > 80 * 1024 ? 256 : 512;          // one or two 512-thread workgroups per CU, persistent over the row tiles
+    int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
+    // persistent over the row tiles: one 16-wave workgroup per CU, or one / two 8-wave ones
+    const int64_t cap = NWV == 16 ? 256 : lds > 80 * 1024 ? 256 : 512;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D>), dim3((unsigned)blocks), dim3(512), lds, s, src, rows, sh, sw, cin, crop_y, crop_x, h,
-                       w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>), dim3((unsigned)blocks), dim3(64 * NWV), lds, s, src, rows, sh, sw, cin, crop_y,
+                       crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
 extern int g_wino_nbw1;
-int g_conv1x1_ring = 0;          // 0: deepest ring that fits and divides the chunk count; 1: one chunk in flight (A/B knob)
+int g_conv1x1_ring = 0;          // A/B knob: 0 = 16-wave workgroups, column blocks of the wide expands split over two waves; 1 = the
+                                 // first layout (8 waves, every wave all column blocks, activation ring as deep as fits)
 
 #define SWK_C1_ARGS s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
 template <int NBLK>
 static int launch_conv1x1(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
                           const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
-    if (cin % 32 == 0) {           // whole 128-byte lines per pixel and chunk
-        const int n = cin / 32, dmax = g_conv1x1_ring == 1 ? 1 : NBLK >= 6 ? 2 : 4;          // ring registers: 16 D; accumulators: 16 NBLK
+    constexpr int CS = NBLK >= 6 ? 2 : 1;          // 64 accumulator registers per wave at most
+    if (g_conv1x1_ring == 0) {
+        if (cin % 32 == 0) return launch_conv1x1_d<NBLK, 32, 1, CS, 16>(SWK_C1_ARGS);          // whole 128-byte lines per pixel and chunk
+        if (cin == 48) return launch_conv1x1_d<NBLK, 48, 1, CS, 16>(SWK_C1_ARGS);              // one pixel = one chunk (192 bytes)
+        return launch_conv1x1_d<NBLK, 16, 1, CS, 16>(SWK_C1_ARGS);
+    }
+    if (cin % 32 == 0) {
+        const int n = cin / 32, dmax = NBLK >= 6 ? 2 : 4;          // ring registers: 16 D; accumulators: 16 NBLK
         const int d = dmax >= 4 && n % 4 == 0 ? 4 : dmax >= 3 && n % 3 == 0 ? 3 : dmax >= 2 && n % 2 == 0 ? 2 : 1;
         switch (d) {
-        case 4: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 4>(SWK_C1_ARGS);
-        case 3: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 3>(SWK_C1_ARGS);
-        case 2: return launch_conv1x1_d<NBLK, 32, 2>(SWK_C1_ARGS);
-        default: return launch_conv1x1_d<NBLK, 32, 1>(SWK_C1_ARGS);
+        case 4: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 4, 1, 8>(SWK_C1_ARGS);
+        case 3: if constexpr (NBLK < 6) return launch_conv1x1_d<NBLK, 32, 3, 1, 8>(SWK_C1_ARGS);
+        case 2: return launch_conv1x1_d<NBLK, 32, 2, 1, 8>(SWK_C1_ARGS);
+        default: return launch_conv1x1_d<NBLK, 32, 1, 1, 8>(SWK_C1_ARGS);
         }
     }
-    if (cin == 48) return launch_conv1x1_d<NBLK, 48, 1>(SWK_C1_ARGS);          // one pixel = one chunk (192 bytes)
-    return launch_conv1x1_d<NBLK, 16, 1>(SWK_C1_ARGS);
+    if (cin == 48) return launch_conv1x1_d<NBLK, 48, 1, 1, 8>(SWK_C1_ARGS);
+    return launch_conv1x1_d<NBLK, 16, 1, 1, 8>(SWK_C1_ARGS);
 }
 #undef SWK_C1_ARGS
 
