@@ -300,6 +300,10 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
  * priority (breaks the lockstep of the two co-resident waves), bit 1 = it also starts late.  A/B knob; results never
  * depend on it. */
 int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags);
+/* Memory order of the float32 network input written by swk_classifier_input(_window) and swk_segment_inputs: 0 (default)
+ * planes [3][side][side] per segment (an NCHW tensor), 1 channels-last [side][side][3] (what the convolution kernels read; a
+ * torch tensor of shape (n, 3, side, side) in torch.channels_last memory format). */
+int32_t swk_set_classifier_input_layout(swk_ctx *ctx, int32_t channels_last);
 /* M-state pass only: the per-iteration stores of the sparse u8 image start once ||Z||_F < factor * tol * ||X||_F
  * (default 16; <= 0 = every pass).  A window that stops although the pass before its last iteration skipped the
  * stores makes the library run the batch again without the speculation, so results never depend on the factor;

@@ -111,6 +111,7 @@ _SIGS = {
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_pass_tuning": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
+    "swk_set_classifier_input_layout": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_method": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
@@ -253,6 +254,10 @@ class Context:
 
     def set_pass_tuning(self, flags):
         self._check(self._lib.swk_set_pass_tuning(self._h, int(flags)))
+
+    def set_classifier_input_layout(self, channels_last):
+        """False: the network input is written as planes (NCHW); True: channels-last (include/swk.h)."""
+        self._check(self._lib.swk_set_classifier_input_layout(self._h, 1 if channels_last else 0))
 
     def set_sparse_speculation(self, factor):
         self._check(self._lib.swk_set_sparse_speculation(self._h, float(factor)))

@@ -61,7 +61,7 @@ struct ResizeLds {
 };
 
 __device__ __forceinline__ void resize_and_emit(ResizeLds &L, const uint8_t *__restrict__ img, int64_t row_stride, int h, int w,
-                                                uint8_t *__restrict__ patch_out, float *__restrict__ net_out, int pad,
+                                                uint8_t *__restrict__ patch_out, float *__restrict__ net_out, int pad, int nhwc,
                                                 const float *mean, const float *sd)
 {
     const int tid = threadIdx.x;
@@ -112,9 +112,11 @@ __device__ __forceinline__ void resize_and_emit(ResizeLds &L, const uint8_t *__r
         // pad = 100 writes the whole 224x224 input; a smaller pad writes the centred (24 + 2 pad)^2 window of it
         // (the receptive-field cropped network reads rows/cols 92..131 only: pad = 8).
         const int side = kOut + 2 * pad;
+        // memory order of the output: planes [c][y][x], or channels-last [y][x][c] (what the convolution kernels read)
         for (int i = tid; i < 3 * side * side; i += 256) {
-            const int c = i / (side * side), rem = i - c * side * side;
-            const int y = rem / side, x = rem - y * side;
+            int c, y, x;
+            if (nhwc) { const int px = i / 3; c = i - 3 * px; y = px / side; x = px - y * side; }
+            else { c = i / (side * side); const int rem = i - c * side * side; y = rem / side; x = rem - y * side; }
             float v = 0.0f;
             if (y >= pad && y < pad + kOut && x >= pad && x < pad + kOut)
                 v = (float)L.out[((y - pad) * kOut + (x - pad)) * 3 + c] / 255.0f;
@@ -125,7 +127,7 @@ __device__ __forceinline__ void resize_and_emit(ResizeLds &L, const uint8_t *__r
 
 __global__ __launch_bounds__(256) void k_classifier_input(const uint8_t *__restrict__ crops, const int64_t *__restrict__ offsets,
                                                           const int32_t *__restrict__ hw, uint8_t *__restrict__ patches,
-                                                          float *__restrict__ net, int pad, float m0, float m1, float m2,
+                                                          float *__restrict__ net, int pad, int nhwc, float m0, float m1, float m2,
                                                           float s0, float s1, float s2)
 {
     __shared__ ResizeLds L;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void k_classifier_input(const uint8_t *__restr
     const int side = kOut + 2 * pad;
     resize_and_emit(L, crops + offsets[seg], (int64_t)w * 3, h, w,
                     patches ? patches + (int64_t)seg * kOut * kOut * 3 : nullptr,
-                    net ? net + (int64_t)seg * 3 * side * side : nullptr, pad, mean, sd);
+                    net ? net + (int64_t)seg * 3 * side * side : nullptr, pad, nhwc, mean, sd);
 }
 
 // ---------------------------------------------------------------------------------
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_segment_inputs(const uint8_t *__restric
                                                         int frame_h, int frame_w, int x0, int y0,
                                                         const swk_segment *__restrict__ segs, const int32_t *__restrict__ offsets,
                                                         int F, int seg_cap, int min_h, int min_w, int first, int count,
-                                                        float *__restrict__ net, int32_t *__restrict__ seg_frame, int pad,
+                                                        float *__restrict__ net, int32_t *__restrict__ seg_frame, int pad, int nhwc,
                                                         float m0, float m1, float m2, float s0, float s1, float s2,
                                                         int32_t *__restrict__ oversize)
 {
@@ -204,17 +206,20 @@ __global__ __launch_bounds__(256) void k_segment_inputs(const uint8_t *__restric
     if (h < 1 || w < 1 || h > kMaxIn || w > kMaxIn) {
         // empty or oversize box: flagged; the input is the blank image
         if (threadIdx.x == 0) atomicAdd(oversize, 1);
-        for (int i = threadIdx.x; i < 3 * side * side; i += 256) o[i] = (0.0f - mean[i / (side * side)]) / sd[i / (side * side)];
+        for (int i = threadIdx.x; i < 3 * side * side; i += 256) {
+            const int c = nhwc ? i % 3 : i / (side * side);
+            o[i] = (0.0f - mean[c]) / sd[c];
+        }
         return;
     }
     resize_and_emit(L, frames + (int64_t)f * frame_stride + (int64_t)r0 * row_stride + (int64_t)c0 * 3, row_stride, h, w,
-                    nullptr, o, pad, mean, sd);
+                    nullptr, o, pad, nhwc, mean, sd);
 }
 
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
-                             uint8_t *patches, float *net, int pad, const float *mean, const float *sd)
+                             uint8_t *patches, float *net, int pad, bool nhwc, const float *mean, const float *sd)
 {
-    hipLaunchKernelGGL(k_classifier_input, dim3(nseg), dim3(256), 0, s, crops, offsets, hw, patches, net, pad,
+    hipLaunchKernelGGL(k_classifier_input, dim3(nseg), dim3(256), 0, s, crops, offsets, hw, patches, net, pad, nhwc ? 1 : 0,
                        mean[0], mean[1], mean[2], sd[0], sd[1], sd[2]);
 }
 
@@ -225,12 +230,12 @@ void launch_segment_prefix(hipStream_t s, const int32_t *nseg, int F, int seg_ca
 
 void launch_segment_inputs(hipStream_t s, const uint8_t *frames, int64_t frame_stride, int64_t row_stride, int frame_h, int frame_w,
                            int x0, int y0, const swk_segment *segs, const int32_t *offsets, int F, int seg_cap, int min_h, int min_w,
-                           int first, int count, float *net, int32_t *seg_frame, int pad, const float *mean, const float *sd,
+                           int first, int count, float *net, int32_t *seg_frame, int pad, bool nhwc, const float *mean, const float *sd,
                            int32_t *oversize)
 {
     if (count < 1) return;
     hipLaunchKernelGGL(k_segment_inputs, dim3(count), dim3(256), 0, s, frames, frame_stride, row_stride, frame_h, frame_w, x0, y0,
-                       segs, offsets, F, seg_cap, min_h, min_w, first, count, net, seg_frame, pad,
+                       segs, offsets, F, seg_cap, min_h, min_w, first, count, net, seg_frame, pad, nhwc ? 1 : 0,
                        mean[0], mean[1], mean[2], sd[0], sd[1], sd[2], oversize);
 }
 

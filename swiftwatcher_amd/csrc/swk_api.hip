@@ -51,6 +51,7 @@ struct swk_ctx {
     int64_t redo_batches = 0;
     int last_eig_sweeps = 0;       // largest IalmWin::sweeps of the last batch (Newton-Schulz iterations, or 100 + Jacobi sweeps)
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
+    int cls_nhwc = 0;              // classifier-input kernels write channels-last ([y][x][c]) instead of planes
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 256.0;      // M-state pass: ||Z|| every other iteration while above 256 x tol (<= 0: every iteration)
@@ -585,6 +586,13 @@ int32_t swk_pinned_free(void *p)
     return hipHostFree(p) == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
+int32_t swk_set_classifier_input_layout(swk_ctx *ctx, int32_t channels_last)
+{
+    if (!ctx || (channels_last != 0 && channels_last != 1)) return SWK_ERR_ARG;
+    ctx->cls_nhwc = channels_last;
+    return SWK_OK;
+}
+
 int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags)
 {
     if (!ctx || flags < 0 || flags > 3) return SWK_ERR_ARG;
@@ -946,7 +954,7 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
     const size_t side = 24 + 2 * (size_t)pad;
     const size_t net_bytes = (size_t)nseg * 3 * side * side * sizeof(float);
     if (net) { if (net_mem == SWK_MEM_DEVICE) dnet = net; else NEED(ctx, SL_CL_NET, net_bytes, dnet); }
-    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, pad, mean, std_);
+    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, pad, ctx->cls_nhwc != 0, mean, std_);
     if (patches) HIPCHK(ctx, hipMemcpyAsync(patches, dpatch, (size_t)nseg * 24 * 24 * 3, hipMemcpyDeviceToHost, s));
     if (net && net_mem != SWK_MEM_DEVICE) HIPCHK(ctx, hipMemcpyAsync(net, dnet, net_bytes, hipMemcpyDeviceToHost, s));
     return sync(ctx);
@@ -983,7 +991,7 @@ int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, i
     if (count > net_cap) count = net_cap;
     if (count < 1) return SWK_OK;
     launch_segment_inputs(s, in->frames, in->frame_stride, in->row_stride, frame_h, frame_w, in->x0, in->y0, segs, doffs, F, seg_cap,
-                          min_h, min_w, first, count, net, seg_frame, pad, mean, std_, dskip);
+                          min_h, min_w, first, count, net, seg_frame, pad, ctx->cls_nhwc != 0, mean, std_, dskip);
     int32_t sk = 0;
     HIPCHK(ctx, hipMemcpyAsync(&sk, dskip, 4, hipMemcpyDeviceToHost, s));
     int rc = sync(ctx);

@@ -107,12 +107,12 @@ void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W,
 
 // classify_input.hip
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
-                             uint8_t *patches, float *net, int pad, const float *mean, const float *sd);
+                             uint8_t *patches, float *net, int pad, bool nhwc, const float *mean, const float *sd);
 
 void launch_segment_prefix(hipStream_t s, const int32_t *nseg, int F, int seg_cap, int32_t *offsets);
 void launch_segment_inputs(hipStream_t s, const uint8_t *frames, int64_t frame_stride, int64_t row_stride, int frame_h, int frame_w,
                            int x0, int y0, const swk_segment *segs, const int32_t *offsets, int F, int seg_cap, int min_h, int min_w,
-                           int first, int count, float *net, int32_t *seg_frame, int pad, const float *mean, const float *sd,
+                           int first, int count, float *net, int32_t *seg_frame, int pad, bool nhwc, const float *mean, const float *sd,
                            int32_t *oversize);
 
 // ccl.hip

@@ -529,7 +529,10 @@ class SegmentClassifier:
         pad = PAD - CroppedSqueezeNet10.IN_LO if self.cropped is not None else PAD
         side = RESIZE + 2 * pad
         bs = self.batch_size
-        x = torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device)
+        # the cropped network's convolution kernels read channels-last: the input is written that way (a copy per forward less)
+        nhwc = self.cropped is not None and self.cropped.memory_format == torch.channels_last
+        x = torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device,
+                        memory_format=torch.channels_last if nhwc else torch.contiguous_format)
         fidx = torch.empty((bs,), dtype=torch.int32, device=self.device)
         scores, frames_of = [], []
         first, total = 0, None
@@ -537,9 +540,13 @@ class SegmentClassifier:
             # the library writes x on its own stream (and waits for it): only PyTorch's reads of the previous chunk have to
             # be over, not the whole device -- another thread may be segmenting the next batch meanwhile
             torch.cuda.current_stream(self.device).synchronize()
-            total, skipped = ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
-                                                IMAGENET_STD, x.data_ptr(), bs, first=first, pad=pad,
-                                                min_seg_size=min_seg_size, seg_frame_ptr=fidx.data_ptr())
+            ctx.set_classifier_input_layout(nhwc)
+            try:
+                total, skipped = ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
+                                                    IMAGENET_STD, x.data_ptr(), bs, first=first, pad=pad,
+                                                    min_seg_size=min_seg_size, seg_frame_ptr=fidx.data_ptr())
+            finally:
+                ctx.set_classifier_input_layout(False)
             if skipped:
                 raise RuntimeError("%d segment boxes were empty or larger than 512 pixels" % skipped)
             k = min(bs, total - first)
