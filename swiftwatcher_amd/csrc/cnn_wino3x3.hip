@@ -62,7 +62,7 @@ __device__ unsigned long long *g_wino_stamp;
 #define SWK_STAMP(k) do { } while (0)
 #endif
 
-template <int NBLK, int NBW, int TGN, int SPP, int WPS>
+template <int NBLK, int NBW, int TGN, int SPP, int WPS, bool PRIV>
 __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_place(const float *__restrict__ src, int nseg, int t, int T,
                                                                       const float *__restrict__ w2, const float *__restrict__ bias, int cout,
                                                                       float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x,
@@ -72,9 +72,16 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
     // PPOS per position
     // a wave owns NBW column blocks of 32 output channels (WPS waves per SIMD fit: NBW = 2 -> 2, NBW = 1 -> 4)
     constexpr int CG = NBLK / NBW, NW = CG * TGN, NT = 64 * NW, CIN = 8 * NBLK, S = CIN / 16, SLOTS = 32 * TGN, VP = SLOTS + 1, G4 = CIN / 4,
-                  NP = 32 * NBLK, CGR = 32 * CG, PHS = S / SPP, PPOS = NBW * PHS, WPH = 16 * SPP * CGR, PPW = WPH / (256 * NW);
+                  NP = 32 * NBLK, CGR = 32 * CG, PHS = S / SPP, PPOS = NBW * PHS;
+    // PRIV (one column block per wave, 64 -> 256): every wave copies the 2 KB of filter operands of a phase that it reads itself
+    // into a slice of its own -- its vmcnt tells it when they have landed, and the workgroup meets only once per position (for
+    // V): 3 % faster there, 5-13 % slower on the narrower shapes.  Otherwise the waves share the copy of a phase (WPH floats,
+    // PPW pieces each) and meet after every phase.
+    static_assert(!PRIV || NBW == 1, "private filter slices: one column block per wave");
+    constexpr int WCG = PRIV ? 32 : CGR;          // output channels side by side in a phase buffer
+    constexpr int WPH = PRIV ? NW * 16 * SPP * 32 : 16 * SPP * CGR, PPW = WPH / (256 * NW);
     static_assert(NBW * NT == SLOTS * G4, "NBW staging items per thread");
-    static_assert(S % SPP == 0 && PPW * NW * 256 == WPH, "whole 1 KB pieces per wave");
+    static_assert(S % SPP == 0 && PPW * NW * 256 == WPH && (!PRIV || SPP == 1), "whole 1 KB pieces per wave");
     extern __shared__ float lds[];                 // W[2][WPH] (filter operands of two phases), V[2][CIN][VP], the bias padded to NP
     float *const W0 = lds, *const W1 = lds + WPH;
     float *const V0 = lds + 2 * WPH, *const V1 = V0 + CIN * VP, *const lbias = V1 + CIN * VP;
@@ -139,10 +146,12 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
     // Written as an asm statement: through __builtin_amdgcn_global_load_lds the compiler treats the copy as an LDS store that
     // every later ds_read may alias and waits for it (s_waitcnt vmcnt(0)) before the very next operand read -- the copy is then
     // no longer asynchronous.  The waits are placed by hand instead (wait_copies(), before the barrier that ends a phase).
-    const unsigned wvoff = (unsigned)((wave * PPW) * 1024 + lane * 16);
+    const unsigned wvoff = PRIV ? (unsigned)(lane * 16) : (unsigned)((wave * PPW) * 1024 + lane * 16);
     const unsigned wpiece = __builtin_amdgcn_readfirstlane((unsigned)(wave * PPW) * 1024u);
+    const int cg_u = __builtin_amdgcn_readfirstlane(cg);
     auto w_issue = [&](int ph, float *Wb) {
-        const float *g = w2 + (int64_t)ph * WPH;          // uniform
+        // shared: the phase's block as it lies; private: this wave's column block of the phase ([phase][cg][512 floats])
+        const float *g = PRIV ? w2 + ((int64_t)ph * CG + cg_u) * 512 : w2 + (int64_t)ph * WPH;          // uniform
         const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Wb) + wpiece;
         unsigned keep;
         if constexpr (PPW == 1)
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
     auto wait_copies = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto wait_copies_keep4 = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
     // this lane's operand quads in a phase buffer: [chunk][k half][quad][CGR channels][4]
-    const int wlane = ((hh * 2) * CGR + cg * 32 + r) * 4;
+    const int wlane = PRIV ? wave * (PPW * 256) + ((hh * 2) * 32 + r) * 4 : ((hh * 2) * CGR + cg * 32 + r) * 4;
     constexpr int CB = 32 * NBW;          // output channels of a wave
 
 #ifdef SWK_WINO_STAMP
@@ -213,15 +222,15 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
             float4 w0[2], w1[2];
             float bv[2][8];
             w0[0] = *(const float4 *)wq;
-            w1[0] = *(const float4 *)(wq + 4 * CGR);
+            w1[0] = *(const float4 *)(wq + 4 * WCG);
 #pragma unroll
             for (int i = 0; i < 8; ++i) bv[0][i] = vrow[i * VP];
 #pragma unroll
             for (int sub = 0; sub < SPP; ++sub) {
                 const int c = sub & 1, n = c ^ 1;
                 if (sub + 1 < SPP) {
-                    w0[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR));
-                    w1[n] = *(const float4 *)(wq + (sub + 1) * (16 * CGR) + 4 * CGR);
+                    w0[n] = *(const float4 *)(wq + (sub + 1) * (16 * WCG));
+                    w1[n] = *(const float4 *)(wq + (sub + 1) * (16 * WCG) + 4 * WCG);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) bv[n][i] = vrow[((sub + 1) * 16 + i) * VP];
                 }
@@ -285,7 +294,9 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
                     if (h == 0 && PHS > 1) wait_copies_keep4();
                     else wait_copies();
                     SWK_STAMP(3);
-                    __syncthreads();          // the LDS-DMA pieces of every wave have landed, the other buffers are free
+                    // shared filter copies: every wave's pieces have landed, the other buffers are free.  Private ones: the
+                    // workgroup meets only when the next position's V is complete
+                    if (!PRIV || q == PPOS - 1) __syncthreads();
                     SWK_STAMP(4);
                 }
             }
@@ -328,15 +339,18 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
 int g_wino_nbw1 = 1;          // A/B knob (swk_set_cnn_tuning 1): one column block per wave (three or four waves per SIMD) or two
 // column blocks per wave of the configuration a shape runs on (the filter layout depends on it)
 static int wino_nbw(int, int) { return g_wino_nbw1 ? 1 : 2; }
+// private per-wave filter slices (their own layout): the 64 -> 256 configuration with one column block per wave
+static bool wino_priv(int cin, int cout) { return cin == 64 && cout == 256 && wino_nbw(cin, cout) == 1; }
 
-template <int NBLK, int NBW, int TGN, int SPP, int WPS>
+template <int NBLK, int NBW, int TGN, int SPP, int WPS, bool PRIV>
 static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const float *w2, const float *bias, int cout, float *dst, int dH,
                           int dW, int dC, int off_y, int off_x, int c_off)
 {
     constexpr int CIN = 8 * NBLK, SLOTS = 32 * TGN, NT = 64 * (NBLK / NBW) * TGN, CGR = 32 * (NBLK / NBW);
-    const size_t lds = (size_t)(2 * 16 * SPP * CGR + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
+    constexpr int WPH = PRIV ? (NT / 64) * 16 * SPP * 32 : 16 * SPP * CGR;
+    const size_t lds = (size_t)(2 * WPH + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS, PRIV>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
     if ((int64_t)n * t * t * CIN * 4 >= ((int64_t)1 << 32)) return SWK_ERR_CAPACITY;          // 32-bit byte offsets into src
     const int T = (t - 2 + 1) / 2;
     const int64_t ntiles = (int64_t)n * T * T;
@@ -345,7 +359,7 @@ static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const f
     // are independent -- one's phase change (drain, update, barrier, first operand reads) is covered by the other's MFMAs
     const int64_t cap = 256 * ((4 * WPS) / (NT / 64));
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW,
+    hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS, PRIV>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW,
                        dC, off_y, off_x, c_off);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
@@ -365,9 +379,9 @@ int32_t swk_wino_stamp_buffer(unsigned long long *buf)
 int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t cin, float *out)
 {
     if (!weight || !out || cout < 1 || cin < 16 || (cin & 15)) return SWK_ERR_ARG;
-    // operand layout of k_wino3x3_relu_place: [p][h][chunk][k half][quad][cg * 32 + r][4] with output channel 32 NBW cg + 32 h + r
-    // (NBW = column blocks per wave of the kernel configuration this shape runs on, h < NBW) and input channel
-    // 16 chunk + 8 (k half) + 4 quad + j; output channels padded to a multiple of 32 NBW
+    // operand layout of k_wino3x3_relu_place, input channel = 16 chunk + 8 (k half) + 4 quad + j, output channels padded to whole
+    // column blocks; NBW = column blocks per wave of the kernel configuration this shape runs on (see the loop below)
+    const bool priv = swk::wino_priv(cin, cout);
     const int NBW = swk::wino_nbw(cin, cout), CB = 32 * NBW, CG = (cout + CB - 1) / CB, CGR = 32 * CG, S = cin / 16;
     static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     for (int64_t i = 0, e = (int64_t)16 * cin * NBW * CGR; i < e; ++i) out[i] = 0.0f;
@@ -382,10 +396,16 @@ int32_t swk_winograd_f2x2_3x3_weights(const float *weight, int32_t cout, int32_t
             const int sub = ci >> 4, hh = (ci >> 3) & 1, q = (ci >> 2) & 1, j = ci & 3;
             const int cg = co / CB, h = (co % CB) >> 5, r = co & 31;
             for (int p = 0; p < 16; ++p) {
-                int64_t idx = (int64_t)p * NBW + h;
-                idx = idx * S + sub;
-                idx = (idx * 2 + hh) * 2 + q;
-                idx = idx * CGR + cg * 32 + r;
+                int64_t idx;
+                if (priv) {              // [p][chunk][cg][k half][quad][r][4]: a wave's 2 KB of a phase are contiguous
+                    idx = ((int64_t)p * S + sub) * CG + cg;
+                    idx = ((idx * 2 + hh) * 2 + q) * 32 + r;
+                } else {                 // [p][h][chunk][k half][quad][cg * 32 + r][4]: the phase's block as it sits in LDS
+                    idx = (int64_t)p * NBW + h;
+                    idx = idx * S + sub;
+                    idx = (idx * 2 + hh) * 2 + q;
+                    idx = idx * CGR + cg * 32 + r;
+                }
                 out[idx * 4 + j] = (float)U[p >> 2][p & 3];
             }
         }
@@ -404,9 +424,9 @@ int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src
     // the squeeze ratio of SqueezeNet's Fire modules: 8 input channels per 32 output channels
 #define SWK_W3_ARGS s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
     const bool one = wino_nbw(cin, cout) == 1;
-    if (cin == 32 && cout == 128) return one ? launch_wino3x3<4, 1, 1, 1, 4>(SWK_W3_ARGS) : launch_wino3x3<4, 2, 2, 2, 2>(SWK_W3_ARGS);
-    if (cin == 48 && cout == 192) return one ? launch_wino3x3<6, 1, 2, 3, 3>(SWK_W3_ARGS) : launch_wino3x3<6, 2, 2, 3, 2>(SWK_W3_ARGS);
-    if (cin == 64 && cout == 256) return one ? launch_wino3x3<8, 1, 1, 1, 4>(SWK_W3_ARGS) : launch_wino3x3<8, 2, 1, 2, 2>(SWK_W3_ARGS);
+    if (cin == 32 && cout == 128) return one ? launch_wino3x3<4, 1, 1, 1, 4, false>(SWK_W3_ARGS) : launch_wino3x3<4, 2, 2, 2, 2, false>(SWK_W3_ARGS);
+    if (cin == 48 && cout == 192) return one ? launch_wino3x3<6, 1, 2, 3, 3, false>(SWK_W3_ARGS) : launch_wino3x3<6, 2, 2, 3, 2, false>(SWK_W3_ARGS);
+    if (cin == 64 && cout == 256) return one ? launch_wino3x3<8, 1, 1, 1, 4, true>(SWK_W3_ARGS) : launch_wino3x3<8, 2, 1, 2, 2, false>(SWK_W3_ARGS);
 #undef SWK_W3_ARGS
     return SWK_ERR_ARG;
 }

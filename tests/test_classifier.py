@@ -383,14 +383,23 @@ def test_fused_conv3x3_kernel_against_torch():
 
 def test_winograd_filter_transform_host():
     """swk_winograd_f2x2_3x3_weights (host code): U = G g G^T of every filter, in the kernel's operand layout
-    [position][column block h of a wave][16-channel chunk][k half][quad][cg * 32 + r][4], output channel 32 NBW cg + 32 h + r
-    (padded to a multiple of 32 NBW), input channel 16 chunk + 8 (k half) + 4 quad + j; NBW = column blocks per wave of the kernel
-    configuration (1 by default, 2 with the measurement knob)."""
+    input channel 16 chunk + 8 (k half) + 4 quad + j, output channels padded to whole column blocks; one layout per kernel
+    configuration: [position][h][chunk][k half][quad][cg * 32 + r][4] with output channel 32 NBW cg + 32 h + r (NBW = 1 column
+    block per wave by default, 2 behind the measurement knob); 64 -> 256 with one block per wave keeps every wave's 2 KB of a phase
+    contiguous: [position][chunk][cg][k half][quad][r][4], output channel 32 cg + r."""
     import ctypes
     from swiftwatcher_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(3)
-    cout, cin = 104, 32
+    for cout, cin in ((104, 32), (256, 64)):
+        _check_winograd_layouts(lib, rng, cout, cin)
+    w = rng.standard_normal((8, 24, 3, 3)).astype(np.float32)
+    out = np.zeros(16, np.float32)
+    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), 8, 24, out.ctypes.data_as(ctypes.c_void_p)) != 0
+
+
+def _check_winograd_layouts(lib, rng, cout, cin):
+    import ctypes
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum("ak,oikl,bl->abio", G, w.astype(np.float64), G)              # [xi][nu][ci][co]
@@ -400,13 +409,16 @@ def test_winograd_filter_transform_host():
             CG = -(-cout // (32 * nbw))
             out = np.full(16 * cin * nbw * 32 * CG, np.nan, np.float32)
             assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
-            out = out.reshape(16, nbw, cin // 16, 2, 2, CG, 32, 4)                   # p, h, chunk, k half, quad, cg, r, j
-            got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 32 * nbw * CG)      # -> [xi][nu][channel][32 NBW cg + 32 h + r]
+            if not (nbw == 1 and (cin, cout) == (64, 256)):         # shared phase blocks: p, h, chunk, k half, quad, cg, r, j
+                out = out.reshape(16, nbw, cin // 16, 2, 2, CG, 32, 4)
+                got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 32 * nbw * CG)      # -> [xi][nu][channel][64 cg + 32 h + r]
+            else:                # 64 -> 256, private slices: a wave's 2 KB of a phase contiguous: p, chunk, cg, k half, quad, r, j
+                out = out.reshape(16, cin // 16, CG, 2, 2, 32, 4)
+                got = out.transpose(0, 1, 3, 4, 6, 2, 5).reshape(4, 4, cin, 32 * CG)               # -> [xi][nu][channel][32 cg + r]
             assert np.array_equal(got[..., :cout], U.astype(np.float32))
             assert not got[..., cout:].any()
     finally:
         assert lib.swk_set_cnn_tuning(1, 1) == 0
-    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, 24, out.ctypes.data_as(ctypes.c_void_p)) != 0
 
 
 @pytest.mark.gpu
