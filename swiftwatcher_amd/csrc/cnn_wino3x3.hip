@@ -424,6 +424,7 @@ int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src
     // the squeeze ratio of SqueezeNet's Fire modules: 8 input channels per 32 output channels
 #define SWK_W3_ARGS s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
     const bool one = wino_nbw(cin, cout) == 1;
+    if (cin == 16 && cout == 64 && one) return launch_wino3x3<2, 1, 2, 1, 4, false>(SWK_W3_ARGS);
     if (cin == 32 && cout == 128) return one ? launch_wino3x3<4, 1, 1, 1, 4, false>(SWK_W3_ARGS) : launch_wino3x3<4, 2, 2, 2, 2, false>(SWK_W3_ARGS);
     if (cin == 48 && cout == 192) return one ? launch_wino3x3<6, 1, 2, 3, 3, false>(SWK_W3_ARGS) : launch_wino3x3<6, 2, 2, 3, 2, false>(SWK_W3_ARGS);
     if (cin == 64 && cout == 256) return one ? launch_wino3x3<8, 1, 1, 1, 4, true>(SWK_W3_ARGS) : launch_wino3x3<8, 2, 1, 2, 2, false>(SWK_W3_ARGS);

@@ -170,6 +170,7 @@ class CroppedSqueezeNet10:
         self.fused_3x3 = os.environ.get("SWK_FUSED_3X3", "1") == "1"
         # wide 3x3 expands (fire4..9) by Winograd F(2x2, 3x3) (csrc/cnn_wino3x3.hip); SWK_WINOGRAD_3X3=0: the direct kernel
         self.fused_wino = os.environ.get("SWK_WINOGRAD_3X3", "1") == "1"
+        self.wino_cin = tuple(int(c) for c in os.environ.get("SWK_WINOGRAD_CIN", "16,32,48,64").split(","))
         self._wt3 = {}
         self._ww3 = {}
 
@@ -192,7 +193,7 @@ class CroppedSqueezeNet10:
             executed += n * n * sq.out_channels * sq.in_channels
             e1_side = crop[1] if (on_gpu and self.fused_1x1) else t      # the fused kernel only computes the rows that are used
             executed += e1_side * e1_side * e1.out_channels * e1.in_channels
-            wino = on_gpu and self.fused_3x3 and self.fused_wino and e3.out_channels == 4 * e3.in_channels and e3.in_channels in (32, 48, 64)
+            wino = on_gpu and self.fused_3x3 and self.fused_wino and e3.out_channels == 4 * e3.in_channels and e3.in_channels in self.wino_cin
             if wino:
                 tiles = ((t - 2 + 1) // 2) ** 2
                 executed += tiles * 16 * e3.out_channels * e3.in_channels
@@ -304,7 +305,7 @@ class CroppedSqueezeNet10:
         def conv3x3(src, j, conv, dest, off, c_off):
             src = nhwc(src)
             cin, cout = conv.in_channels, conv.out_channels
-            if self.fused_wino and cout == 4 * cin and cin in (32, 48, 64):
+            if self.fused_wino and cout == 4 * cin and cin in self.wino_cin and k * src.shape[2] * src.shape[2] * cin * 4 < (1 << 32):
                 ww = self._ww3.get(j)
                 if ww is None:       # G g G^T in the kernel's operand layout, once per layer (host code of the library)
                     w = conv.weight.detach().to("cpu", torch.float32).contiguous()

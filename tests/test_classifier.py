@@ -435,9 +435,10 @@ def test_winograd_conv3x3_kernel_against_torch():
     cases = [  # n, cin, cout, t, dH, off, dC, c_off
         (3, 32, 128, 16, 17, 1, 256, 128), (9, 32, 128, 12, 10, 0, 256, 128), (2, 48, 192, 14, 12, 0, 384, 192),
         (3, 48, 192, 16, 14, 0, 384, 192), (2, 64, 256, 18, 19, 2, 512, 256), (5, 64, 256, 13, 11, 0, 512, 256),
-        (1, 64, 256, 3, 1, 0, 256, 0), (1, 32, 128, 5, 3, 0, 128, 0), (70, 64, 256, 7, 5, 0, 256, 0), (33, 48, 192, 4, 2, 0, 192, 0)]
+        (1, 64, 256, 3, 1, 0, 256, 0), (1, 32, 128, 5, 3, 0, 128, 0), (70, 64, 256, 7, 5, 0, 256, 0), (33, 48, 192, 4, 2, 0, 192, 0),
+        (7, 16, 64, 12, 10, 0, 128, 64), (5, 16, 64, 14, 12, 0, 128, 64), (130, 16, 64, 5, 3, 0, 64, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    for knob, (n, cin, cout, t, dH, off, dC, c_off) in [(1, c) for c in cases] + [(0, c) for c in cases[:6]]:
+    for knob, (n, cin, cout, t, dH, off, dC, c_off) in [(1, c) for c in cases] + [(0, c) for c in cases[:6]]:          # 16 -> 64 only with one block per wave
         assert lib.swk_set_cnn_tuning(1, knob) == 0          # one (default) or two column blocks per wave: different kernels and layouts
         x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         wcpu = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).contiguous()
@@ -469,5 +470,5 @@ def test_winograd_conv3x3_kernel_against_torch():
         assert bool((dst[mask] == -7.0).all())
     assert lib.swk_set_cnn_tuning(1, 1) == 0
     # shapes outside the Fire ratio are refused (the caller takes the direct kernel)
-    assert lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), 1, 4, 16, ww.data_ptr(), bias.data_ptr(), 64,
-                                                         dst.data_ptr(), 2, 2, 64, 0, 0, 0) != 0
+    assert lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), 1, 4, 16, ww.data_ptr(), bias.data_ptr(), 32,
+                                                         dst.data_ptr(), 2, 2, 32, 0, 0, 0) != 0

@@ -8,7 +8,7 @@ lib = _lib.load()
 dev = torch.device("cuda", 0)
 n = 4096
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-for cin, cout, t in ((64, 256, 18), (48, 192, 16), (48, 192, 14), (32, 128, 16)):
+for cin, cout, t in ((64, 256, 18), (48, 192, 16), (48, 192, 14), (32, 128, 16), (16, 64, 14), (16, 64, 12)):
     x = torch.randn((n, t, t, cin), device=dev)
     w = torch.randn((cout, cin, 3, 3)) * 0.05
     ww = torch.empty(16 * cin * cout)
