@@ -141,6 +141,7 @@ class CroppedSqueezeNet10:
                 self.plan.append(("pool", layer, tile, lo - n0, hi - lo + 1, None, None))
                 lo, hi, size = a, b, out_size
         self.final = (lo, hi, size)
+        self.final_bg = x[:, :, lo:hi + 1, lo:hi + 1].contiguous()          # the last Fire's output for the blank image, live square
         ring = head.clone()
         ring[:, :, lo:hi + 1, lo:hi + 1] = 0
         self.ring_sum = ring.sum(dim=(2, 3))                 # (1, 2): the head's input-independent positions
@@ -191,7 +192,7 @@ class CroppedSqueezeNet10:
             t = tile.shape[2] + pad[0] + pad[1]
             sq, e1, e3 = layer.squeeze, layer.expand1x1, layer.expand3x3
             executed += n * n * sq.out_channels * sq.in_channels
-            e1_side = crop[1] if (on_gpu and self.fused_1x1) else t      # the fused kernel only computes the rows that are used
+            e1_side = n if (on_gpu and self.fused_1x1) else t      # the fused kernel only computes the outputs that depend on the segment
             executed += e1_side * e1_side * e1.out_channels * e1.in_channels
             wino = on_gpu and self.fused_3x3 and self.fused_wino and e3.out_channels == 4 * e3.in_channels and e3.in_channels in self.wino_cin
             if wino:
@@ -223,9 +224,15 @@ class CroppedSqueezeNet10:
         for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
             nxt = self.plan[j + 1][0] if j + 1 < len(self.plan) else "head"
             if kind == "fire" and nxt != "pool":
-                c_out = layer.expand1x1.out_channels + layer.expand3x3.out_channels
-                live.append(torch.empty((batch, c_out, crop[1], crop[1]), dtype=torch.float32, device=tile.device)
-                            .contiguous(memory_format=self.memory_format))
+                # initialised with the blank image's values: the expand1x1 outputs on the ring of the square (squeeze values that do
+                # not depend on the segment) are never recomputed, a forward writes the expand1x1 centre and all of expand3x3
+                if nxt == "fire":
+                    _, _, ntile, noff, nn, _, _ = self.plan[j + 1]
+                    bg = ntile[:, :, noff:noff + nn, noff:noff + nn]
+                else:
+                    bg = self.final_bg
+                assert bg.shape[2] == crop[1] and bg.shape[1] == layer.expand1x1.out_channels + layer.expand3x3.out_channels
+                live.append(bg.expand(batch, -1, -1, -1).contiguous(memory_format=self.memory_format))
             else:
                 live.append(None)
         self._buf, self._cap = (bufs, live), batch
@@ -360,7 +367,9 @@ class CroppedSqueezeNet10:
                 # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
                 # (csrc/cnn_conv1x1.hip)
                 conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
-                conv1x1(sq, c, cn, layer.expand1x1, dest, doff, 0)
+                # expand1x1 only where the squeeze output depends on the segment (n x n inside the cn x cn square: the ring keeps the
+                # blank image's values the buffers were created with)
+                conv1x1(sq, off, n, layer.expand1x1, dest, doff + off - c, 0)
             else:
                 place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
                 e1 = conv2d(sq, layer.expand1x1.weight, None)
