@@ -214,6 +214,13 @@ int32_t swk_nhwc_bias_relu_place(void *stream, const float *src, int32_t n, int3
                                  int32_t crop_x, int32_t h, int32_t w, const float *bias, float *dst, int32_t dH, int32_t dW,
                                  int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h, int32_t w, int32_t c, float *dst);
+/* conv7x7s2_bias_relu: the network's first convolution (Conv2d(3, 96, 7, stride 2), no padding) with bias and ReLU on the f32 matrix
+ * cores, for the m x m outputs starting at output (lo, lo) of a side x side channels-last input:
+ *   dst[n][y][x][co] = max(sum src[n][2 (lo + y) + dy][2 (lo + x) + dx][c] * weight[co][c][dy][dx] + bias[co], 0)
+ * src [n][side][side][3] (side even, 2 (lo + m - 1) + 8 <= side: a zero-weighted eighth patch row is read), weight the Conv2d weight
+ * [96][3][7][7] in plain (contiguous) layout, dst [n][m][m][96]. */
+int32_t swk_nhwc_conv7x7s2_bias_relu(void *stream, const float *src, int32_t n, int32_t side, int32_t lo, int32_t m, const float *weight,
+                                     const float *bias, int32_t cout, float *dst);
 /* conv1x1_bias_relu_place: a 1 x 1 convolution fused with everything up to the next layer's tile (the squeeze and expand1x1
  * convolutions of a Fire module), on the f32 matrix cores:
  *   dst[n][off_y+y][off_x+x][c_off+co] = max(sum_ci src[n][crop_y+y][crop_x+x][ci] * weight[co][ci] + bias[co], 0)

@@ -171,6 +171,8 @@ class CroppedSqueezeNet10:
         self.fused_3x3 = os.environ.get("SWK_FUSED_3X3", "1") == "1"
         # wide 3x3 expands (fire4..9) by Winograd F(2x2, 3x3) (csrc/cnn_wino3x3.hip); SWK_WINOGRAD_3X3=0: the direct kernel
         self.fused_wino = os.environ.get("SWK_WINOGRAD_3X3", "1") == "1"
+        self.fused_conv1 = os.environ.get("SWK_FUSED_CONV1", "1") == "1"
+        self._w1 = None
         self.wino_cin = tuple(int(c) for c in os.environ.get("SWK_WINOGRAD_CIN", "16,32,48,64").split(","))
         self._wt3 = {}
         self._ww3 = {}
@@ -343,10 +345,21 @@ class CroppedSqueezeNet10:
 
         aux = self._aux_buffers(k)
         conv1 = m.features[0]
-        e = conv2d(nhwc(tiles), conv1.weight, None, stride=conv1.stride)
         a, b = self.pool1_slice
         c1buf = aux["conv1"][:k]
-        place(e, conv1.bias, c1buf, a, b - a, 0, 0)
+        side = tiles.shape[2]
+        if self.fused_conv1 and conv1.out_channels == 96 and side % 2 == 0 and 2 * (b - 1) + 8 <= side:
+            # conv1 + bias + ReLU on the rows the first pool reads, one kernel (csrc/cnn_conv1.hip)
+            if self._w1 is None:
+                self._w1 = conv1.weight.detach().contiguous(memory_format=torch.contiguous_format).clone()
+            xin = nhwc(tiles)
+            rc = lib.swk_nhwc_conv7x7s2_bias_relu(stream, xin.data_ptr(), k, side, a, b - a, self._w1.data_ptr(), conv1.bias.data_ptr(),
+                                                  conv1.out_channels, c1buf.data_ptr())
+            if rc:
+                raise RuntimeError("swk_nhwc_conv7x7s2_bias_relu failed (%d)" % rc)
+        else:
+            e = conv2d(nhwc(tiles), conv1.weight, None, stride=conv1.stride)
+            place(e, conv1.bias, c1buf, a, b - a, 0, 0)
         x = aux["pool_in"][:k]
         pool(c1buf, x)
         pi = 0
@@ -485,15 +498,17 @@ class SegmentClassifier:
 
     @torch.no_grad()
     def _bucket(self, k):
-        """Batch size the network is run at for k inputs: MIOpen searches for kernels once per tensor shape (seconds),
-        and a counting loop hands over a different number of segments every call -- so on the GPU the batch is
-        padded to one of three sizes (64, 512, batch_size).  The padding rows are scored and thrown away."""
+        """Batch size the network is run at for k inputs: MIOpen searches for kernels once per tensor shape (seconds; conv1 and
+        the head are its), and a counting loop hands over a different number of segments every call -- so on the GPU the
+        batch is padded to 64, or to a multiple of 512 up to batch_size (at most batch_size / 512 + 1 shapes).  The padding
+        rows are scored and thrown away."""
         if self.device.type != "cuda":
             return k
-        for b in (64, 512):
-            if k <= b < self.batch_size:
-                return b
-        return max(self.batch_size, k)
+        if k <= 64 < self.batch_size:
+            return 64
+        if k >= self.batch_size:
+            return max(self.batch_size, k)
+        return min(self.batch_size, -(-k // 512) * 512)
 
     def _run(self, x, k):
         """Scores of the first k rows of x (x has _bucket(k) rows)."""

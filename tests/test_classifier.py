@@ -343,6 +343,33 @@ def test_fused_conv1x1_kernel_against_torch():
 
 
 @pytest.mark.gpu
+def test_fused_conv1_kernel_against_torch():
+    """swk_nhwc_conv7x7s2_bias_relu (the 7 x 7 stride-2 first convolution + bias + ReLU on the f32 matrix cores, patch rows split
+    between the MFMA's k halves) against torch.nn.functional.conv2d: the cropped network's 40 x 40 window, a crop inside a larger
+    image, batches that do not fill the last row tile."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(26)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, side, lo, m in ((5, 40, 0, 17), (3, 64, 4, 9), (1, 8, 0, 1), (130, 22, 1, 7)):
+        x = torch.randn((n, 3, side, side), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn((96, 3, 7, 7), generator=g) * (2.0 / 147) ** 0.5).to(dev).contiguous()
+        bias = (torch.randn((96,), generator=g) * 0.3).to(dev)
+        y = torch.relu(torch.nn.functional.conv2d(x, w, bias, stride=2))[:, :, lo:lo + m, lo:lo + m]
+        dst = torch.full((n, 96, m, m), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        torch.cuda.synchronize()
+        rc = lib.swk_nhwc_conv7x7s2_bias_relu(stream, x.data_ptr(), n, side, lo, m, w.data_ptr(), bias.data_ptr(), 96, dst.data_ptr())
+        assert rc == 0, (rc, n, side, lo, m)
+        torch.cuda.synchronize()
+        scale = max(float(y.abs().max()), 1.0)
+        assert float((dst - y).abs().max()) <= 2e-5 * scale, (n, side, lo, m)
+    # an output whose patch would leave the image is refused
+    assert lib.swk_nhwc_conv7x7s2_bias_relu(stream, x.data_ptr(), 1, 22, 1, 8, w.data_ptr(), bias.data_ptr(), 96, dst.data_ptr()) != 0
+
+
+@pytest.mark.gpu
 def test_fused_conv3x3_kernel_against_torch():
     """swk_nhwc_conv3x3_bias_relu_place (valid 3 x 3 convolution over the squeeze tile + bias + ReLU + placement behind the
     expand1x1 channels, weights streamed through LDS) against torch.nn.functional.conv2d: every (channels, tile) shape the

@@ -56,6 +56,9 @@ def describe(name, a):
         n, h, w, c = a[2], a[3], a[4], a[5]
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         return "pool %3d %2dx%2d" % (c, h, w), 0, 4 * n * c * (h * w + oh * ow)
+    if name == "swk_nhwc_conv7x7s2_bias_relu":
+        n, side, m = a[2], a[3], a[5]
+        return "7x7s2  3-> 96 %2dx%2d" % (m, m), n * m * m * 147 * 96, 4 * n * (side * side * 3 + m * m * 96)
     if name == "swk_nhwc_bias_relu_place":
         n, c, h, w = a[2], a[5], a[8], a[9]
         return "place %3d %2dx%2d" % (c, h, w), 0, 8 * n * c * h * w

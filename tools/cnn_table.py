@@ -27,8 +27,7 @@ groups = [
     ("`k_conv3x3_relu_place<2,4>` (fire2, fire3: 16 → 64, direct)", lambda n: "k_conv3x3_relu_place" in n, 2.25e6),
     ("`k_conv1x1_relu_place<…>` (8 squeeze + 8 expand1x1)", lambda n: "k_conv1x1_relu_place" in n, 23.5e6),
     ("`k_maxpool3s2` × 3", lambda n: "k_maxpool3s2" in n, 0),
-    ("conv1 (7×7, stride 2, 3 → 96: MIOpen/CK kernel) + `k_bias_relu_place`",
-     lambda n: "kernel_grouped_conv_fwd_multiple_abd" in n or "k_bias_relu_place" in n, 4.08e6),
+    ("`k_conv7x7s2_relu` (conv1: 7×7, stride 2, 3 → 96, + bias + ReLU)", lambda n: "k_conv7x7s2_relu" in n, 4.08e6),
     ("head (512 → 2, CK kernel)", lambda n: "kernel_grouped_conv_fwd_xdl_cshuffle" in n, 0.12e6),
 ]
 print("| kernel(s) | per forward | per step (×%d) | direct-convolution MACs per segment | rate (direct-equivalent) |" % cnn["forwards_per_step"])
