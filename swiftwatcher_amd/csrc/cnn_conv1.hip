@@ -23,7 +23,7 @@ namespace swk {
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(512, 4) void k_conv7x7s2_relu(const float *__restrict__ src, int64_t rows, int side, int lo, int m,
-                                                        const float *__restrict__ wgt, const float *__restrict__ bias, float *__restrict__ dst)
+                                                        const float *__restrict__ wgt, const float *__restrict__ bias, float *__restrict__ dst, FastDiv fmm, FastDiv fm)
 {
     constexpr int NB = 3, NP = 96, PITCH = NP + 1, KR = 21;          // column blocks, channels, LDS pitch, floats per patch row
     extern __shared__ float lds[];                                   // weights [4 dy][21 j][2 halves][PITCH], then the bias
@@ -43,11 +43,10 @@ __global__ __launch_bounds__(512, 4) void k_conv7x7s2_relu(const float *__restri
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
         const int64_t q = tile * 32 + r;
         const bool valid = q < rows;
-        const int64_t qq = valid ? q : rows - 1;
-        const int64_t b = qq / mm2;
-        const int rem = (int)(qq - b * mm2), y = rem / m, x = rem - y * m;
+        const unsigned qq = valid ? (unsigned)q : (unsigned)rows - 1u;          // rows < 2^31 (checked by the launcher)
+        const unsigned b = fmm.div(qq), rem = qq - b * (unsigned)mm2, y = fm.div(rem), x = rem - y * (unsigned)m;
         // patch row 0 (half 0) or 4 (half 1) of this pixel
-        const float *p = src + ((b * side + 2 * (lo + y) + 4 * hh) * (int64_t)side + 2 * (lo + x)) * 3;
+        const float *p = src + (((int64_t)b * side + 2 * (lo + y) + 4 * hh) * (int64_t)side + 2 * (lo + x)) * 3;
         f16v acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -119,9 +118,11 @@ int32_t swk_nhwc_conv7x7s2_bias_relu(void *stream, const float *src, int32_t n, 
     static unsigned long long attr_mask = 0;
     if (!ensure_dyn_lds((const void *)k_conv7x7s2_relu, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
     const int64_t rows = (int64_t)n * m * m, ntiles = (rows + 31) / 32;
+    if (rows > (int64_t)0x7fffff00) return SWK_ERR_CAPACITY;
     int64_t blocks = (ntiles + 7) / 8;
     if (blocks > 512) blocks = 512;          // two 8-wave workgroups per CU (65 KB of LDS each), persistent over the row tiles
-    hipLaunchKernelGGL(k_conv7x7s2_relu, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, src, rows, side, lo, m, weight, bias, dst);
+    hipLaunchKernelGGL(k_conv7x7s2_relu, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, src, rows, side, lo, m, weight, bias, dst,
+                       FastDiv((unsigned)(m * m)), FastDiv((unsigned)m));
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 

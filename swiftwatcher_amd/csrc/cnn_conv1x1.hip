@@ -36,7 +36,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 template <int NBLK, int KC, int D, int CS, int NWV>
 __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__restrict__ src, int64_t rows, int sh, int sw, int cin, int crop_y,
                                                             int crop_x, int h, int w, const float *__restrict__ wgt, const float *__restrict__ bias,
-                                                            int cout, float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
+                                                            int cout, float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x, int c_off,
+                                                            FastDiv fhw, FastDiv fw)
 {
     constexpr int NP = 32 * NBLK, PITCH = NP + 1, KH = KC / 2, NV = KH / 4, NB = NBLK / CS, NT = 64 * NWV, SLOTS = NWV / CS;
     static_assert(NBLK % CS == 0 && NWV % CS == 0, "column splits");
@@ -50,14 +51,13 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__
 
     // source pointer and destination offset of this lane's pixel in a row tile (rows past the end repeat the last one)
     auto locate = [&](int64_t t, int64_t &ro) -> const float * {
-        const int64_t m = t * 32 + r;
-        const bool valid = m < rows;
-        const int64_t mm = valid ? m : rows - 1;
-        const int64_t b = mm / hw;
-        const int rem = (int)(mm - b * hw);
-        const int y = rem / w, x = rem - y * w;
-        ro = valid ? ((b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off + 32 * NB * cs : -1;
-        return src + ((b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + KH * hh;
+        const unsigned m = (unsigned)t * 32u + (unsigned)r;          // rows < 2^31 (checked by the launcher): invariant-divisor division
+        const bool valid = m < (unsigned)rows;
+        const unsigned mm = valid ? m : (unsigned)rows - 1u;
+        const unsigned b = fhw.div(mm), rem = mm - b * (unsigned)hw;
+        const unsigned y = fw.div(rem), x = rem - y * (unsigned)w;
+        ro = valid ? (((int64_t)b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off + 32 * NB * cs : -1;
+        return src + (((int64_t)b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + KH * hh;
     };
     float4 a[D][NV];
     int64_t ro = -1, ro_next = -1;
@@ -150,7 +150,7 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     const size_t lds = (size_t)(((cin * (32 * NBLK + 1) + 3) & ~3) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
     if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
-    if (lds > 160 * 1024 - 256) return SWK_ERR_CAPACITY;
+    if (lds > 160 * 1024 - 256 || rows > (int64_t)0x7fffff00) return SWK_ERR_CAPACITY;
     constexpr int SLOTS = NWV / CS;
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
@@ -158,7 +158,7 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     const int64_t cap = NWV == 16 ? 256 : lds > 80 * 1024 ? 256 : 512;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>), dim3((unsigned)blocks), dim3(64 * NWV), lds, s, src, rows, sh, sw, cin, crop_y,
-                       crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
+                       crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off, FastDiv((unsigned)(h * w)), FastDiv((unsigned)w));
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 

@@ -66,7 +66,7 @@ template <int NBLK, int NBW, int TGN, int SPP, int WPS, bool PRIV>
 __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_place(const float *__restrict__ src, int nseg, int t, int T,
                                                                       const float *__restrict__ w2, const float *__restrict__ bias, int cout,
                                                                       float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x,
-                                                                      int c_off)
+                                                                      int c_off, FastDiv fTT, FastDiv fT)
 {
     // S k-chunks of 16 channels per position; a phase = SPP of them for one column block: PHS phases per (position, column block),
     // PPOS per position
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
         for (int k = 0; k < NBW; ++k) {
             int64_t m = task * SLOTS + sslot[k];
             if (m >= ntiles) m = ntiles - 1;
-            const int64_t b = m / TT;
-            const int rem = (int)(m - b * TT), ty = rem / T, tx = rem - ty * T;
+            const unsigned bu = fTT.div((unsigned)m), rem = (unsigned)m - bu * (unsigned)TT, ty = fT.div(rem), tx = rem - ty * (unsigned)T;
+            const int64_t b = bu;          // ntiles < 2^31 (checked by the launcher): invariant-divisor division
             const int64_t base = (((b * t + 2 * ty) * t + 2 * tx) * (int64_t)CIN + 4 * sg[k]) * 4;
             const int64_t lim = src_floats * 4 - 16 - base;          // a patch may reach one row / column past an odd-sized tile
             sbase[k] = (unsigned)base;
@@ -197,8 +197,9 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
         const int64_t m = task * SLOTS + tg * 32 + r;
         const bool valid = m < ntiles;
         const int64_t mm = valid ? m : ntiles - 1;
-        const int64_t b = mm / TT;
-        const int rem = (int)(mm - b * TT), ty = rem / T, tx = rem - ty * T;
+        const unsigned bu = fTT.div((unsigned)mm), rem = (unsigned)mm - bu * (unsigned)TT;
+        const int ty = (int)fT.div(rem), tx = (int)(rem - (unsigned)ty * (unsigned)T);
+        const int64_t b = bu;
         const int64_t ro = ((b * dH + off_y + 2 * ty) * dW + off_x + 2 * tx) * (int64_t)dC + c_off + CB * cg + 4 * hh;
         const bool vy1 = 2 * ty + 1 < o, vx1 = 2 * tx + 1 < o;
         const bool more = task + gridDim.x < ntasks;
@@ -351,7 +352,7 @@ static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const f
     const size_t lds = (size_t)(2 * WPH + 2 * CIN * (SLOTS + 1) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
     if (!ensure_dyn_lds((const void *)k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS, PRIV>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
-    if ((int64_t)n * t * t * CIN * 4 >= ((int64_t)1 << 32)) return SWK_ERR_CAPACITY;          // 32-bit byte offsets into src
+    if ((int64_t)n * t * t * CIN * 4 >= ((int64_t)1 << 32)) return SWK_ERR_CAPACITY;          // 32-bit byte offsets into src (and tile indices)
     const int T = (t - 2 + 1) / 2;
     const int64_t ntiles = (int64_t)n * T * T;
     int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
@@ -360,7 +361,7 @@ static int launch_wino3x3(hipStream_t s, const float *src, int n, int t, const f
     const int64_t cap = 256 * ((4 * WPS) / (NT / 64));
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_wino3x3_relu_place<NBLK, NBW, TGN, SPP, WPS, PRIV>), dim3((unsigned)blocks), dim3(NT), lds, s, src, n, t, T, w2, bias, cout, dst, dH, dW,
-                       dC, off_y, off_x, c_off);
+                       dC, off_y, off_x, c_off, FastDiv((unsigned)(T * T)), FastDiv((unsigned)T));
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 

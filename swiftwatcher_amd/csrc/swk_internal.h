@@ -25,6 +25,31 @@ inline bool ensure_dyn_lds(const void *fn, size_t bytes, unsigned long long &mas
 }
 inline void note_launch() { hipError_t e = hipGetLastError(); if (e != hipSuccess) g_launch_error = (int)e; }
 
+// Division of a 31-bit dividend by a launch-invariant divisor as one multiply-high and a shift (a 64-bit integer division is some
+// 150 vector instructions on gfx950, a 32-bit one 30 -- and in the matrix kernels every vector instruction is paid in MFMA time).
+// For n < 2^31 and d >= 1: l = ceil(log2 d), mul = floor(2^(31+l) / d) + 1, n / d = umulhi(n, mul) >> (l - 1); d = 1 is the identity.
+struct FastDiv {
+    unsigned mul, shift, d;
+    FastDiv() : mul(0), shift(0), d(1) {}
+    explicit FastDiv(unsigned div) : mul(0), shift(0), d(div)
+    {
+        if (div > 1) {
+            unsigned l = 0;
+            while ((1ull << l) < div) ++l;
+            mul = (unsigned)(((1ull << (31 + l)) / div) + 1);
+            shift = l - 1;
+        }
+    }
+    __host__ __device__ unsigned div(unsigned n) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return d == 1 ? n : __umulhi(n, mul) >> shift;
+#else
+        return n / d;
+#endif
+    }
+};
+
 // Per-window scalar state of the IALM loop (device resident).
 struct IalmScal { double mu, inv_mu, thr; };
 struct IalmWin {
