@@ -31,8 +31,8 @@
 //     those loads, SQ_WAIT_ANY / SQ_WAVE_CYCLES, and the matrix pipe was 43 % busy.)
 //   * MFMA roles as in cnn_conv1x1.hip: weights = A operand, tiles = B operand, so a register quad of an accumulator is four
 //     consecutive output channels of the lane's own tile: float4 stores.
-// Where it stands (MI355X, batch 4096, tools/bench_convs.py): 64 -> 256 on 16 x 16 outputs 1.36 ms against 2.63 ms for the
-// direct kernel; the matrix pipe is 65 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the f32 vector instructions that share it
+// Where it stands (MI355X, batch 4096, tools/bench_convs.py): 64 -> 256 on 16 x 16 outputs 1.30-1.34 ms against 2.63 ms for the
+// direct kernel; the matrix pipe is 70 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the f32 vector instructions that share it
 // (profiles/r2_f32_pipe_probe.txt) another 10 %; s_memtime brackets (tools/wino_stamp.py) put a wave's remaining time into
 // the barrier (19 %) and the phase prologue / epilogue; skipping the global loads altogether gains 9 %.
 // Launched on the CALLER's stream (PyTorch's current stream).
