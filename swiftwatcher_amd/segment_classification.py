@@ -556,30 +556,41 @@ class SegmentClassifier:
         bs = self.batch_size
         # the cropped network's convolution kernels read channels-last: the input is written that way (a copy per forward less)
         nhwc = self.cropped is not None and self.cropped.memory_format == torch.channels_last
-        x = torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device,
-                        memory_format=torch.channels_last if nhwc else torch.contiguous_format)
-        fidx = torch.empty((bs,), dtype=torch.int32, device=self.device)
-        scores, frames_of = [], []
-        first, total = 0, None
-        while total is None or first < total:
-            # the library writes x on its own stream (and waits for it): only PyTorch's reads of the previous chunk have to
-            # be over, not the whole device -- another thread may be segmenting the next batch meanwhile
-            torch.cuda.current_stream(self.device).synchronize()
+        # two input buffers: the library cuts and resamples chunk i + 1 (on its own stream, and waits for it) while PyTorch's
+        # stream runs the network on chunk i; a buffer is written again only after the forward that read it has finished
+        xb = [torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device,
+                          memory_format=torch.channels_last if nhwc else torch.contiguous_format) for _ in range(2)]
+        fb = [torch.empty((bs,), dtype=torch.int32, device=self.device) for _ in range(2)]
+        done = [None, None]
+
+        def produce(slot, first):
+            if done[slot] is not None:
+                done[slot].synchronize()
             ctx.set_classifier_input_layout(nhwc)
             try:
                 total, skipped = ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
-                                                    IMAGENET_STD, x.data_ptr(), bs, first=first, pad=pad,
-                                                    min_seg_size=min_seg_size, seg_frame_ptr=fidx.data_ptr())
+                                                    IMAGENET_STD, xb[slot].data_ptr(), bs, first=first, pad=pad,
+                                                    min_seg_size=min_seg_size, seg_frame_ptr=fb[slot].data_ptr())
             finally:
                 ctx.set_classifier_input_layout(False)
             if skipped:
                 raise RuntimeError("%d segment boxes were empty or larger than 512 pixels" % skipped)
+            return total
+
+        scores, frames_of = [], []
+        total = produce(0, 0)
+        first, i = 0, 0
+        while first < total:
+            slot = i & 1
             k = min(bs, total - first)
-            if k <= 0:
-                break
-            scores.append(self._run(x[:self._bucket(k)], k).clone())     # rows past k hold an earlier chunk: scored, dropped
-            frames_of.append(fidx[:k].clone())
+            scores.append(self._run(xb[slot][:self._bucket(k)], k).clone())     # rows past k hold an earlier chunk: scored, dropped
+            frames_of.append(fb[slot][:k].clone())
+            done[slot] = torch.cuda.Event()
+            done[slot].record(torch.cuda.current_stream(self.device))
             first += k
+            i += 1
+            if first < total:
+                produce(i & 1, first)
         if not scores:
             return torch.zeros((0, 2), device=self.device), torch.zeros((0,), dtype=torch.int32, device=self.device)
         return torch.cat(scores), torch.cat(frames_of)
