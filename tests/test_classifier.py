@@ -343,6 +343,35 @@ def test_fused_conv1x1_kernel_against_torch():
 
 
 @pytest.mark.gpu
+def test_own_kernels_match_miopen_path_at_bench_batch(tmp_path):
+    """The cropped network on the library's own kernels (conv1, 1 x 1, Winograd 3 x 3, pools) against the same network with every
+    convolution on MIOpen, at a ragged batch of the bench's size (2,377 rows: row tiles, Winograd tasks and workgroups that end in
+    the middle of a segment) and at a single row; then the direct 3 x 3 kernel in place of the Winograd one."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    path = tmp_path / "w.pt"
+    torch.save(ref.random_state_dict(11), path)
+    clf = SegmentClassifier(str(path), batch_size=4096)
+    net = clf.cropped
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for rows in (2377, 1):
+        x = torch.randn((rows, 3, 40, 40), generator=g).cuda()
+        with torch.no_grad():
+            own = net(x).clone()
+            flags = (net.fused_conv1, net.fused_1x1, net.fused_3x3, net.fused_wino)
+            try:
+                net.fused_wino = False
+                direct = net(x).clone()
+                net.fused_conv1 = net.fused_1x1 = net.fused_3x3 = False
+                miopen = net(x).clone()
+            finally:
+                net.fused_conv1, net.fused_1x1, net.fused_3x3, net.fused_wino = flags
+        scale = float(miopen.abs().max()) + 1e-6
+        assert float((own - miopen).abs().max()) <= 2e-5 * max(scale, 1.0), rows
+        assert float((direct - miopen).abs().max()) <= 2e-5 * max(scale, 1.0), rows
+
+
+@pytest.mark.gpu
 def test_fused_conv1_kernel_against_torch():
     """swk_nhwc_conv7x7s2_bias_relu (the 7 x 7 stride-2 first convolution + bias + ReLU on the f32 matrix cores, patch rows split
     between the MFMA's k halves) against torch.nn.functional.conv2d: the cropped network's 40 x 40 window, a crop inside a larger
