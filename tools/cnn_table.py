@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 line = json.load(open(sys.argv[2]))
 cnn = line["roofline_cnn"]
-batch = 4096
+rows_per_forward = cnn["rows_per_step"] / cnn["forwards_per_step"]          # the last forward of a step is a partial one
 
 
 def total(pred):
@@ -30,13 +30,13 @@ groups = [
     ("`k_conv7x7s2_relu` (conv1: 7×7, stride 2, 3 → 96, + bias + ReLU)", lambda n: "k_conv7x7s2_relu" in n, 4.08e6),
     ("head (512 → 2, CK kernel)", lambda n: "kernel_grouped_conv_fwd_xdl_cshuffle" in n, 0.12e6),
 ]
-print("| kernel(s) | per forward | per step (×%d) | direct-convolution MACs per segment | rate (direct-equivalent) |" % cnn["forwards_per_step"])
+print("| kernel(s) | per forward (%d rows on average) | per step (×%d) | direct-convolution MACs per segment | rate (direct-equivalent) |" % (round(rows_per_forward), cnn["forwards_per_step"]))
 print("|---|---|---|---|---|")
 s = 0.0
 for name, pred, macs in groups:
     per = per_forward(pred, fwd)
     s += per
-    rate = "%.0f TFLOP/s" % (2 * macs * batch / (per * 1e-3) / 1e12) if macs and per > 0 else ""
+    rate = "%.0f TFLOP/s" % (2 * macs * rows_per_forward / (per * 1e-3) / 1e12) if macs and per > 0 else ""
     print("| %s | %.2f ms | %.1f ms | %s | %s |" % (name, per, per * cnn["forwards_per_step"], ("%.1f M" % (macs / 1e6)) if macs else "—", rate))
 ev = cnn["net_ms_per_step"] / cnn["forwards_per_step"]
 print("| remainder: ReLU / sum / decision of the head (PyTorch element-wise kernels), gaps | ≈%.2f ms | ≈%.1f ms | | |" % (ev - s, (ev - s) * cnn["forwards_per_step"]))
