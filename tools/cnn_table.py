@@ -39,7 +39,7 @@ for name, pred, macs in groups:
     rate = "%.0f TFLOP/s" % (2 * macs * rows_per_forward / (per * 1e-3) / 1e12) if macs and per > 0 else ""
     print("| %s | %.2f ms | %.1f ms | %s | %s |" % (name, per, per * cnn["forwards_per_step"], ("%.1f M" % (macs / 1e6)) if macs else "—", rate))
 ev = cnn["net_ms_per_step"] / cnn["forwards_per_step"]
-print("| remainder: ReLU / sum / decision of the head (PyTorch element-wise kernels), gaps | ≈%.2f ms | ≈%.1f ms | | |" % (ev - s, (ev - s) * cnn["forwards_per_step"]))
+print("| remainder: ReLU / sum / decision of the head (PyTorch element-wise kernels), gaps | ≈%.2f ms | ≈%.1f ms | | |" % (max(ev - s, 0.0), max(ev - s, 0.0) * cnn["forwards_per_step"]))
 print("| **sum** (HIP events around the forwards) | **%.2f ms** | **%.1f ms** | %.1f M useful, %.1f M executed | %.1f TFLOP/s executed = **%.2f of 157.3**; %.1f direct-equivalent |"
       % (ev, cnn["net_ms_per_step"], cnn["macs_per_segment_useful"] / 1e6, cnn["macs_per_segment_executed"] / 1e6, cnn["achieved"], cnn["frac"],
          cnn["direct_equivalent"]["achieved"]))
