@@ -80,6 +80,9 @@ struct MCfg {
     static constexpr int TP = 17;                                  // LDS pitch of the transpose tile
     static constexpr int NPAIR = NB * (NB + 1) / 2;
     static constexpr size_t lds_bytes = (size_t)(NPAD * BP + 4 * NPAD * TP) * sizeof(double);
+    // the first-iteration pass (MODE 1) appends two 256-entry tables (M_1 and U_0 as functions of the pixel value): + 4 KB, which at
+    // 64 frames makes a workgroup exactly half of the CU's 160 KB
+    static constexpr size_t lut_bytes = 2 * 256 * sizeof(double);
 };
 
 constexpr unsigned ROWSTEP = 128u;           // (4 t) * ROWSTEP = t * 512 elements: one chunk of M / U per k-step
@@ -89,6 +92,7 @@ constexpr unsigned ROWSTEP = 128u;           // (4 t) * ROWSTEP = t * 512 elemen
 struct PassCtx {
     __amdgpu_buffer_rsrc_t rX, rS, rM, rU;
     double *sB, *sT;
+    const double *lut;          // MODE 1: [256] M_1(x), then [256] U_0(x) = Y_0(x) / mu_0
     double inv_mu, thr, inv_mu2, thr2, dual, rdual, ratio;
     float ratio_f;
     unsigned P32, fpad;
@@ -139,12 +143,7 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
         if (MODE == 1) {
             // first iteration: A_0 = 0 (:273) and Y_0 = X / dual (:272), so M_1 is a function of X alone
 #pragma unroll
-            for (int t = 0; t < NK; ++t) {
-                const double x = (double)xi[t];
-                const double u0 = cx.inv_mu * y0_of(x);
-                const double e = shrink2(x + u0, cx.thr);                             // :282-283
-                mv[t] = (x - e) + u0;                                              // :284
-            }
+            for (int t = 0; t < NK; ++t) mv[t] = cx.lut[xi[t]];          // a function of the 8-bit value alone: tabulated (kernel prologue)
         }
         // ---- A_k^T = B^T M_k^T on the matrix cores, ONE out-frame block at a time: a wave that has the matrix pipe to
         //      itself issues back-to-back MFMAs on one accumulator every 72 cycles, on two alternating ones every 76, on
@@ -181,7 +180,7 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                     const double pk = mv[t] - a_new;                               // M_k - A_k = Y_k / mu_{k-1}  (:293-294)
                     raw = __builtin_fma(pk, cx.ratio, x - a_new);                  // :282, (X - A_k) + Y_k / mu_k
                     if (MODE == 1) {
-                        const float zf = (float)(pk - cx.inv_mu * y0_of(x)) * kUScale;   // :293 with U_0 = Y_0 / mu_0, in units of 128
+                        const float zf = (float)(pk - cx.lut[256 + xi[t]]) * kUScale;   // :293 with U_0 = Y_0 / mu_0, in units of 128
                         if (t == 0) zz0 += zf * zf; else zz += zf * zf;
                         if (t == 0 || WU) pkf = (float)pk;
                     } else if (t == 0 || RU || WU) {
@@ -279,6 +278,19 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
             sB[k * BP + c] = (k < n && c < n) ? Bm[k * n + c] : 0.0;
         }
     }
+    // first iteration: M_1 = (x - E_1) + U_0 with U_0 = Y_0 / mu_0, Y_0 = x / dual (:272, the correctly rounded quotient by one
+    // Newton step) and E_1 = shrink(x + U_0) (:282-284) depend on the pixel's 8-bit value only: 256 threads tabulate them once
+    // (the same operations in the same order as the element-wise code they replace: 11 f64 instructions per element less)
+    double *lut = lds + NPAD * BP + 4 * NPAD * TP;
+    if (MODE == 1) {
+        const double x = (double)tid;
+        const double q = x * rdual;
+        const double y0 = __builtin_fma(__builtin_fma(-q, dual, x), rdual, q);
+        const double u0 = inv_mu * y0;
+        const double e = shrink2(x + u0, thr);
+        lut[tid] = (x - e) + u0;
+        lut[256 + tid] = u0;
+    }
     // frame rows 4 NK .. NPAD - 1 of the transpose tile are never written: they must read as zeros in the Gram phase
     for (int i = lane; i < (NPAD - 4 * NK) * TP; i += 64) sT[4 * NK * TP + i] = 0.0;
     __syncthreads();
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
     const int ntiles = (P + 15) >> 4;
     const int nsteps = 2 * ((((ntiles + 7) >> 3) - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
 
-    PassCtx cx{rX, rS, rM, rU, sB, sT, inv_mu, thr, inv_mu2, thr2, dual, rdual, ratio, ratio_f, P32, (unsigned)b.fpad,
+    PassCtx cx{rX, rS, rM, rU, sB, sT, lut, inv_mu, thr, inv_mu2, thr2, dual, rdual, ratio, ratio_f, P32, (unsigned)b.fpad,
                pl, fr0, wave, ntiles, nsteps, (int)blockIdx.x, (int)gridDim.x};
     // the per-window switches of this pass (sparse-image stores, all of U read / written) are wave-uniform but only
     // known on the device: one specialised copy of the tile loop per combination, chosen once
@@ -355,8 +367,9 @@ template <int NK, int MODE>
 static void launch_m_one(hipStream_t s, const IalmBuffers &b, int sel, int tune)
 {
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_ialm_pass_m<NK, MODE>, MCfg<NK>::lds_bytes, attr_mask)) return;
-    hipLaunchKernelGGL((k_ialm_pass_m<NK, MODE>), dim3(b.nblk, b.nwin), dim3(256), MCfg<NK>::lds_bytes, s, b, sel, tune);
+    constexpr size_t lds = MCfg<NK>::lds_bytes + (MODE == 1 ? MCfg<NK>::lut_bytes : 0);
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_m<NK, MODE>, lds, attr_mask)) return;
+    hipLaunchKernelGGL((k_ialm_pass_m<NK, MODE>), dim3(b.nblk, b.nwin), dim3(256), lds, s, b, sel, tune);
     note_launch();
 }
 
