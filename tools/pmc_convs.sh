@@ -8,6 +8,8 @@ run() { name=$1; shift; timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM
 run sq3 SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES
+run fetch FETCH_SIZE GRBM_COUNT
+run write WRITE_SIZE GRBM_COUNT
 python3 tools/pmc_summary.py "$out" "$out/summary.json" > "$out/summary.txt" 2>&1
-rm -rf "$out"/sq1 "$out"/sq2 "$out"/sq3
+rm -rf "$out"/sq1 "$out"/sq2 "$out"/sq3 "$out"/fetch "$out"/write
 grep -A 30 "wino3x3_relu_place<8" "$out/summary.txt" | head -40
