@@ -76,7 +76,11 @@ def run(name, seed, fps, start, end, n_events, clump):
 if __name__ == "__main__":
     cases = [run("short_30fps", 1, 30.0, 0, 300, 14, True),          # < 1 minute: the per-minute table prints dates only
              run("long_2997", 2, 29.97, 0, 4000, 40, True),          # > 2 minutes, fractional microseconds
-             run("offset_start_60fps", 3, 60.0, 120, 2000, 9, False)]
+             run("offset_start_60fps", 3, 60.0, 120, 2000, 9, False),
+             # start * 1e9 / fps with a fractional nanosecond: pandas casts it to int64 (truncation), which moves one or two
+             # rows of the per-microsecond table by 1 us against a rounding restatement
+             run("offset_start_2997", 6, 29.97, 17, 1234, 12, True),      # (seed 4 has no rejected event: the reference's combine_first raises under pandas 2.x)
+             run("offset_start_23976", 5, 23.976, 17, 900, 8, False)]
     json.dump(dict(pandas=pd.__version__, numpy=np.__version__, cases=cases), open(OUT, "w"), indent=0)
     for c in cases:
         print(c["name"], "total", c["total"], "files", list(c["files"]), "labels", sum(c["labels"]), "/", len(c["labels"]))

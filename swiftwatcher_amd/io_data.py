@@ -20,17 +20,12 @@ import numpy as np
 NS = 1_000_000_000
 
 
-def _round_half_even(x):
-    """Python's round() on a float: to the nearest integer, ties to even -- what pandas' cast_from_unit does for unit 'ns'."""
-    return int(round(x))
-
-
 def _timedelta_ns(value, unit_ns):
     """pandas.Timedelta(float value, unit) in nanoseconds (tslibs/conversion cast_from_unit): integer part exact, fraction
-    rounded to the unit's nanosecond digits, then truncated."""
+    rounded to the unit's nanosecond digits, then truncated.  For unit 'ns' there are no digits to round to: the float is
+    cast to int64, i.e. truncated (Timedelta(33366666.6667, 'ns').value == 33366666 under pandas 2.3.3)."""
     if unit_ns == 1:
-        base = int(value)
-        return base + int(round(value - base, 0))
+        return int(value)
     base = int(value)
     frac = round(value - base, 9)
     return base * unit_ns + int(frac * unit_ns)

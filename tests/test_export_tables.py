@@ -19,7 +19,7 @@ def cases(golden_dir):
     return json.load(open(os.path.join(golden_dir, "export_tables.json")))["cases"]
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4])
 def test_tables_match_the_reference_files(cases, idx, tmp_path):
     from swiftwatcher_amd import event_classification as ec, io_data
     from swiftwatcher_amd.io_frames import ArrayReader
@@ -47,6 +47,24 @@ def test_reader_timestamps_are_the_table_keys():
         table = io_data.create_empty_table(fps, 0, 5000)
         for f in (0, 1, 2, 77, 1234, 4999, 5000):
             assert (io_data.frame_timestamp_ns(f, fps), f) in table, (fps, f)
+
+
+def test_empty_table_equals_pandas_for_offset_starts():
+    """create_empty_table against the reference's statements (io_data.py:33-48) run on the installed pandas, for starts
+    whose start * 1e9 / fps has a fractional nanosecond (pandas truncates it; 3 of 63 combinations differed by 1 us when the
+    restatement rounded)."""
+    pd = pytest.importorskip("pandas")
+    from swiftwatcher_amd import io_data
+    midnight = pd.Timestamp("00:00:00.000000")
+    for fps in (29.97, 59.94, 23.976, 30.0, 29.97002997):
+        for start, end in ((17, 1234), (100, 4421), (17, 900), (1234, 1300)):
+            nano = (1 / fps) * 1e9
+            count = end - start + 1
+            first = midnight + pd.Timedelta(start * nano, "ns")
+            last = first + pd.Timedelta((count - 1) * nano, "ns")
+            stamps = pd.date_range(start=first, end=last, periods=count).round(freq="us")
+            expect = [(int(t.value - midnight.value), f) for t, f in zip(stamps, range(start, end + 1))]
+            assert list(io_data.create_empty_table(fps, start, end)) == expect, (fps, start, end)
 
 
 def test_formatting_rules():
