@@ -14,15 +14,23 @@ __main__.py:77-85 for the whole batch.  value = ROI frames/s over all ranks.
 After the headline loop a second timed loop runs the image_filtering part alone (BASELINE configs[1] as worded:
 "image_filtering HIP kernels") and reports it, with the streaming kernel's roofline, under "segment_only".
 
+After that, on rank 0 at N = 1, the reference's own call pattern is timed from host 1080p frames (sub-results, never `value`):
+"drop_in" = FrameQueue() as the CLI constructs it, push + preprocess_queue + segment_queue per 21-frame window
+(__main__.py:73-78); "count_loop" = swift_counting_algorithm (__main__.py:56-100) with the classifier ON (the calibrated head),
+tracker and events; "pcie_inclusive" = a segment step fed from host memory.
+
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            (starts N ranks itself: one fresh process per GPU, RCCL; this process never touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract fields + "roofline" + "roofline_cnn" + "segment_only" + "cpu_baseline").
+Prints ONE JSON line on rank 0 (contract fields + "roofline" + "roofline_cnn" + "segment_only" + "drop_in" + "count_loop" +
+"pcie_inclusive" + "cpu_baseline").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -71,8 +79,61 @@ def parse():
     ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
-    ap.add_argument("--host-input", action="store_true", help="also time a segment step fed from host memory (PCIe inclusive)")
+    ap.add_argument("--host-input", action="store_true", help="(default at N = 1) kept for compatibility: pcie_inclusive is part of the line")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in / count_loop / pcie_inclusive sub-results (kernel A/Bs)")
+    ap.add_argument("--loop-windows", type=int, default=16, help="21-frame windows of the count_loop clip (1080p frames in host memory: 130 MB each)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher rehearsal without any GPU work: the ranks join the process group (SWK_DIST_BACKEND, gloo on CPU-only "
+                         "hosts), run the barrier / max-over-ranks clock / count gather around EMPTY steps and print the line with value 0")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process -- which must not touch a GPU (a process that has initialised HIP
+    may not exec or fork safely) -- starts N fresh interpreters, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, what
+    torch.distributed.run would set), relays rank 0's JSON line and returns the worst exit code."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SWK_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def rehearse(args):
+    """--rehearse-launch: everything of the multi-rank protocol except the GPU work (CPU test of the launcher; gloo)."""
+    import torch.distributed as dist
+    from swiftwatcher_amd import distributed as swd
+    rank, world, local = swd.init(os.environ.get("SWK_DIST_BACKEND", "gloo"))
+    swd.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    swd.barrier()
+    dt = swd.max_over_ranks(time.perf_counter() - t0)
+    frames = args.windows * args.n * args.steps
+    table = swd.gather_counts({rank: (0, 0, frames)}, world)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (segment+classify) on 1080p ROI batches", "value": 0.0, "unit": "frames/s",
+                          "n_gpus": world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 6),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none", "rehearsal": True,
+                          "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "launched_by": "bench.py" if os.environ.get("SWK_BENCH_LAUNCHED") else "external launcher",
+                          "per_rank": [{"rank": int(r), "frames": int(table[r, 2])} for r in range(world)]}), flush=True)
+    if world > 1:
+        swd.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
@@ -136,8 +197,74 @@ def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
     return out
 
 
+def reference_call_pattern(ctx_device, clf, args, geo):
+    """The reference's own call pattern from host 1080p frames (rank 0, N = 1): sub-results of the line, never `value`."""
+    import numpy as np
+    from swiftwatcher_amd import pipeline, synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    from swiftwatcher_amd.io_frames import ArrayReader
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd import image_filtering as img
+    corners = [(790, 620), (1130, 622)]                                  # SURVEY 8d: the 340-px chimney of a 1080p frame
+    crop_region = img.generate_crop_region(corners)                      # [(748, 452), (1172, 664)]: 424 x 212
+    n = 21
+    out = {}
+    # ---- drop_in: FrameQueue() exactly as __main__.py:67 constructs it; per window push + preprocess + segment (:73-78) ----
+    frames = synthetic.full_frames(3, n, crop_region)
+    order = [frames[i] for i in range(n - 1, -1, -1)]
+    numbers, stamps = list(range(n)), ["t"] * n
+    q = FrameQueue()
+    times, nseg = [], 0
+    for rep in range(34):
+        t0 = time.perf_counter()
+        q.push_list_of_frames(order, numbers, stamps)
+        q.preprocess_queue(crop_region, (300, 150))
+        q.segment_queue((24, 24), crop_region)
+        times.append(time.perf_counter() - t0)
+        nseg = sum(len(f.segments) for f in q)
+        while not q.is_empty():
+            q.pop_frame()
+    t = sum(times[4:]) / len(times[4:])
+    out["drop_in"] = {"what": "FrameQueue() with its default constructor (stage images kept, on the GPU until read): push_list_of_frames + "
+                              "preprocess_queue + segment_queue per 21-frame window from host 1080p frames, Python Frame / Segment objects made",
+                      "value": round(n / t, 1), "unit": "frames/s", "ms_per_window": round(t * 1e3, 3), "windows_timed": len(times) - 4,
+                      "segments_per_window": nseg, "ialm_iters": q.last_iters}
+    del frames, order, q
+    # ---- count_loop: swift_counting_algorithm (__main__.py:56-100), classifier ON (the bench's calibrated head), tracker, events ----
+    total = n * args.loop_windows
+    clip = synthetic.full_frames(5, total, crop_region, birds=12)[::-1]          # oldest first
+    flist = [clip[i] for i in range(total)]
+    roi_mask = np.zeros((212, 424), np.uint8)
+    roi_mask[100:, 42:382] = 255
+    loop = {}
+    for name, kw in (("reference_pattern", dict()), ("windows_per_call_8", dict(windows_per_call=8))):
+        for timed in (False, True):                                      # first run = warm-up (shapes, pools, MIOpen find)
+            reader = ArrayReader(flist if timed else flist[:4 * n])
+            t0 = time.perf_counter()
+            events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=clf, keep_stages=True, **kw)
+            dt = time.perf_counter() - t0
+        loop[name] = {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_window": round(dt / args.loop_windows * 1e3, 3),
+                      "events": len(events), "count": int(ec.count_swifts(events))}
+    reader = ArrayReader(flist)
+    t0 = time.perf_counter()
+    events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=None, keep_stages=True)
+    dt = time.perf_counter() - t0
+    loop["reference_pattern_no_classify"] = {"value": round(total / dt, 1), "unit": "frames/s", "events": len(events),
+                                             "count": int(ec.count_swifts(events))}
+    out["count_loop"] = dict(loop["reference_pattern"],
+                             what="swift_counting_algorithm as __main__.py:56-100 runs it: get_n_frames -> FrameQueue() -> classifier(frame.segments) "
+                                  "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory, --classify on (the "
+                                  "bench's calibrated head)" % total,
+                             windows_per_call_8=loop["windows_per_call_8"], no_classify=loop["reference_pattern_no_classify"])
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    if args.rehearse_launch:
+        return rehearse(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -149,6 +276,8 @@ def main():
     # RCCL ("nccl" on ROCm); no-op for a single process.  SWK_DIST_BACKEND=gloo lets several ranks share one GPU
     # for rehearsals (RCCL refuses two ranks on one device).
     rank, world, local = swd.init(os.environ.get("SWK_DIST_BACKEND", "nccl"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -246,6 +375,8 @@ def main():
             kept_total[0] = int(per_frame.sum().item())
             kept_total[1] = int(scores.shape[0])
 
+    own_dt = [0.0]
+
     def fence():
         torch.cuda.synchronize()
         swd.barrier()
@@ -264,6 +395,7 @@ def main():
             fn()
         fence()
         dt = time.perf_counter() - t0
+        own_dt[0] = dt if fn is step else own_dt[0]
         prof = ctx.prof()
         bpe = ctx.pass_bytes_per_element
         ctx.prof_enable(False)
@@ -329,6 +461,8 @@ def main():
     # every rank is one "video" here: (segments kept or found, IALM iterations, frames processed)
     table = swd.gather_counts({rank: (kept_total[0] if clf else int(nseg_host.sum()), int(it_host.sum()), F * args.steps)}, world)
     total_frames = int(table[:, 2].sum())
+    # per-rank clocks (each rank's own elapsed time of the headline loop), gathered the same way
+    rank_ms = swd.gather_counts({rank: (int(round(own_dt[0] * 1e6)), 0, 0)}, world)[:, 0]
 
     if rank == 0:
         elems = n * P
@@ -362,16 +496,18 @@ def main():
             tiles = (P + 15) // 16
             flop = float(it_host.sum()) * args.steps * tiles * mfma_per_tile * 2048.0
             f64_tflops = flop / (pass_ms * 1e-3) / 1e12 if pass_ms > 0 else 0.0
-            return {"bound": "hbm", "kernel": "ialm_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # What bounds the kernel: the f64 execution unit.  f64 MFMAs and f64 vector instructions share it on gfx950
+            # (profiles/r2_f64_pipe_probe.txt), the PMC balance of a launch is 69 % MFMA + 17 % VALU busy; HBM is the second floor and
+            # is reported beside it ("hbm").  achieved = executed MFMA flops (2 x 16 x 16 x 4 per instruction) / launch time.
+            return {"bound": "mfma", "bound_detail": "f64 execution unit (v_mfma_f64_16x16x4_f64 + f64 VALU share one pipe); HBM right behind",
+                    "kernel": "ialm_pass", "achieved": round(f64_tflops, 2), "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(f64_tflops / F64_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)},
                     "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
                     "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
                     "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
                     "pass_variant": variant,
-                    # where the kernel really sits: f64 MFMAs and f64 vector instructions share one execution unit on
-                    # gfx950 (profiles/r2_f64_pipe_probe.txt), so the matrix pipe's share of the launch is a second floor
-                    "f64_matrix_pipe": {"achieved": round(f64_tflops, 2), "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(f64_tflops / F64_MATRIX_PEAK_TFLOPS, 4), "mfma_per_tile": mfma_per_tile},
+                    "mfma_per_tile": mfma_per_tile,
                     # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
                     # replaces): informational, NOT what "achieved" uses
                     "survey_pricing": {"bytes_per_element_iteration": 33,
@@ -387,7 +523,8 @@ def main():
             "metric": "frames/sec (segment+classify) on 1080p ROI batches" if clf else "frames/sec (segment) on 1080p ROI batches",
             "value": round(total_frames / dt_max, 2),
             "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (image_filtering), f32 (CNN)" if clf else "f64", "data": "synthetic",
@@ -401,6 +538,9 @@ def main():
                                        kept_total[1], kept_total[0])) if clf else "off (--no-classify)",
                        "parallelism": "windows sharded per GPU, no data-path collective"},
             "redo_batches": int(redo),
+            "per_rank": [{"rank": r, "frames": int(table[r, 2]), "frames_per_s": round(float(table[r, 2]) / max(float(rank_ms[r]) * 1e-6, 1e-9), 1),
+                          "kept_or_found": int(table[r, 0]), "ialm_iterations": int(table[r, 1])} for r in range(world)],
+            "launched_by": "bench.py" if os.environ.get("SWK_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
             "roofline": pass_roofline(prof, bpe),
             "kernel_ms_per_step": kernel_ms(prof),
         }
@@ -429,14 +569,24 @@ def main():
             res["segment_only"] = {"metric": "frames/sec (segment) on 1080p ROI batches", "value": round(total_frames / so_dt, 2),
                                    "ms_per_step": round(so_dt / args.steps * 1e3, 3), "roofline": pass_roofline(so_prof, so_bpe),
                                    "kernel_ms_per_step": kernel_ms(so_prof)}
-        if args.host_input:
-            host = frames.cpu().numpy()
-            hin = _lib.Input(frames=host.ctypes.data, mem=_lib.MEM_HOST, channels=3, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
+        if world == 1 and not args.no_drop_in:
+            # the same segment step fed from host memory (ROI frames in page-locked memory, one copy per batch), 32 windows
+            hw_ = min(nwin, 32)
+            host = _lib.pinned_empty((hw_ * n, Hc, Wc, 3), np.uint8, device=local)
+            host[...] = frames[:hw_ * n].cpu().numpy()
+            hin = _lib.Input(frames=host.ctypes.data, mem=_lib.MEM_HOST, channels=3, nwin=hw_, n=n, Hc=Hc, Wc=Wc,
                              x0=0, y0=0, frame_stride=P * 3, row_stride=Wc * 3)
             ctx.batch_run_raw(hin, params, out)
             t1 = time.perf_counter()
-            ctx.batch_run_raw(hin, params, out)
-            res["pcie_inclusive_segment_frames_per_s"] = round(F / (time.perf_counter() - t1), 2)
+            for _ in range(3):
+                ctx.batch_run_raw(hin, params, out)
+            dt_h = (time.perf_counter() - t1) / 3
+            res["pcie_inclusive"] = {"what": "segment step with the BGR ROI frames in page-locked HOST memory (%d windows x %d frames, one "
+                                             "host -> device copy per batch inside the timed region)" % (hw_, n),
+                                     "value": round(hw_ * n / dt_h, 1), "unit": "frames/s", "input_gb_per_s": round(hw_ * n * P * 3 / dt_h / 1e9, 2)}
+            del host
+            if args.size == "P2":
+                res.update(reference_call_pattern(local, clf, args, geo))
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
         print(json.dumps(res), flush=True)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWK_ABI_VERSION 1
+#define SWK_ABI_VERSION 2
 
 enum {
     SWK_OK = 0,
@@ -39,7 +39,8 @@ enum {
     SWK_ERR_HIP = -2,       /* a HIP runtime call failed                    */
     SWK_ERR_NOGPU = -3,     /* no usable gfx950 device                      */
     SWK_ERR_CAPACITY = -4,  /* request exceeds what the context was sized for */
-    SWK_ERR_NOMEM = -5
+    SWK_ERR_NOMEM = -5,
+    SWK_ERR_STALE = -6      /* the batch a call refers to is no longer held by the context */
 };
 
 enum { SWK_MEM_HOST = 0, SWK_MEM_DEVICE = 1 };
@@ -119,6 +120,10 @@ typedef struct swk_output {
     int32_t *iters;         /* [nwin] IALM iterations executed */
     int32_t *nseg;          /* [nwin*n] regions found per frame (may exceed seg_cap) */
     swk_segment *segs;      /* [nwin*n][seg_cap], ascending label */
+    int32_t planes_on_device; /* nonzero: the six u8 planes above are DEVICE pointers even when mem = SWK_MEM_HOST
+                               (FrameQueue keeps the stage images on the GPU and copies one only when somebody reads
+                               it, data_structures.py:183-208 stores them but the counting loop never looks) */
+    int32_t reserved_;
 } swk_output;
 
 /* ---- lifecycle ---------------------------------------------------------------- */
@@ -133,9 +138,16 @@ const char *swk_last_error(const swk_ctx *ctx);   /* ctx may be NULL: last creat
 int64_t swk_ctx_device_bytes(const swk_ctx *ctx);
 
 /* Page-locked host memory for staging buffers the caller fills and then passes as swk_input.frames (SWK_MEM_HOST): the
- * copy to the device is then a single DMA.  No context needed; free with swk_pinned_free. */
-int32_t swk_pinned_alloc(int64_t bytes, void **out);
+ * copy to the device is then a single DMA.  Allocated on `device` (the GPU the buffer will be copied to; a thread that never
+ * chose a device would otherwise create a context on GPU 0), usable from any; no swk_ctx needed; free with swk_pinned_free. */
+int32_t swk_pinned_alloc(int32_t device, int64_t bytes, void **out);
 int32_t swk_pinned_free(void *p);
+/* Device memory on the context's GPU for outputs the caller wants to keep there (swk_output with planes_on_device, or
+ * mem = SWK_MEM_DEVICE), and a synchronous copy of a piece of it to host memory.  The library never frees such a buffer
+ * by itself; swk_device_free waits for the context's stream first. */
+int32_t swk_device_alloc(swk_ctx *ctx, int64_t bytes, void **out);
+int32_t swk_device_free(swk_ctx *ctx, void *p);
+int32_t swk_device_read(swk_ctx *ctx, const void *src_device, void *dst_host, int64_t bytes);
 
 /* ---- the hot path --------------------------------------------------------------
  * Replaces, for a batch of windows, FrameQueue.preprocess_queue + segment_queue
@@ -190,7 +202,10 @@ int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_b
  * swiftwatcher_amd/segment_classification.py reads. */
 int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
                                     const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
-                                    int32_t pad, uint8_t *patches, float *net, int32_t net_mem);
+                                    int32_t pad, int32_t channels_last, uint8_t *patches, float *net, int32_t net_mem);
+/* channels_last: memory order of the float32 network input: 0 = planes [3][side][side] per segment (an NCHW tensor),
+ * 1 = [side][side][3] (what the library's convolution kernels read; a torch tensor of shape (n, 3, side, side) in
+ * torch.channels_last memory format).  swk_classifier_input writes planes. */
 
 /* Classifier inputs cut on the device from the frames and region records of a swk_batch_run with device buffers
  * (in->mem = SWK_MEM_DEVICE, BGR; segs / nseg / net / seg_frame are device pointers): segment k of the batch is
@@ -202,8 +217,18 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
  * *skipped = boxes that were empty or larger than 512 pixels (their input is the blank image). */
 int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, int32_t frame_w,
                            const swk_segment *segs, const int32_t *nseg, int32_t seg_cap, int32_t min_h, int32_t min_w,
-                           const float mean[3], const float std_[3], int32_t pad, int32_t first, int32_t net_cap,
-                           float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped);
+                           const float mean[3], const float std_[3], int32_t pad, int32_t channels_last, int32_t first,
+                           int32_t net_cap, float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped);
+/* The same for the LAST swk_batch_run of the context, from what that call left on the device: its frames (the copy the
+ * library made of a SWK_MEM_HOST input, or the caller's device frames, which must still be alive) and its region records.
+ * A host input that carries a margin around the ROI (x0, y0 > 0 in a densely packed buffer: the library then uploads the
+ * whole buffer) lets boxes grow into that margin like extract_segment_images grows them into the full frame
+ * (image_filtering.py:338-369): with a margin of min_seg_size / 2 (or up to the frame's edge) every crop equals the
+ * reference's.  This is how SegmentClassifier scores all segments of a FrameQueue window in one batch at the window's
+ * first classifier call (__main__.py:84-85).  SWK_ERR_STALE when another call has reused the buffers since. */
+int32_t swk_segment_inputs_last(swk_ctx *ctx, int32_t min_h, int32_t min_w, const float mean[3], const float std_[3],
+                                int32_t pad, int32_t channels_last, int32_t first, int32_t net_cap, float *net,
+                                int32_t *seg_frame, int32_t *total, int32_t *skipped);
 
 /* Glue of the receptive-field cropped classifier, launched on the CALLER's HIP stream (PyTorch's current stream;
  * no context): channels-last dense float32 tensors, (n, c, h, w) = memory [n][h][w][c], c multiple of 4.
@@ -231,9 +256,8 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 
-/* Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the
- * 1 x 1 kernel (0 = deepest that fits, 1 = one chunk in flight); knob 1: the Winograd kernel's 64 -> 256 configuration (1 = one
- * column block per wave, four waves per SIMD, the default; 0 = two blocks, two waves) -- set it before the filter transform. */
+/* Measurement knob of the classifier kernels (A/B runs; results never depend on it).  knob 0: workgroup layout of the 1 x 1
+ * kernel (0 = 16-wave workgroups, the default; 1 = 8 waves with the deepest activation ring that fits). */
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value);
 
 /* conv3x3_bias_relu_place: the 3 x 3 expand convolution of a Fire module as a VALID convolution over the t x t squeeze tile
@@ -307,10 +331,6 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
  * priority (breaks the lockstep of the two co-resident waves), bit 1 = it also starts late.  A/B knob; results never
  * depend on it. */
 int32_t swk_set_pass_tuning(swk_ctx *ctx, int32_t flags);
-/* Memory order of the float32 network input written by swk_classifier_input(_window) and swk_segment_inputs: 0 (default)
- * planes [3][side][side] per segment (an NCHW tensor), 1 channels-last [side][side][3] (what the convolution kernels read; a
- * torch tensor of shape (n, 3, side, side) in torch.channels_last memory format). */
-int32_t swk_set_classifier_input_layout(swk_ctx *ctx, int32_t channels_last);
 /* M-state pass only: the per-iteration stores of the sparse u8 image start once ||Z||_F < factor * tol * ||X||_F
  * (default 16; <= 0 = every pass).  A window that stops although the pass before its last iteration skipped the
  * stores makes the library run the batch again without the speculation, so results never depend on the factor;

@@ -10,7 +10,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWK_LIB", os.path.join(_HERE, "libswk.so"))     # SWK_LIB: A/B another build of the same ABI
 
+ABI_VERSION = 2
 MEM_HOST, MEM_DEVICE = 0, 1
+ERR_STALE = -6
+STAGES = ("gray", "rpca", "bilateral", "thresh", "opened", "labels")
 ORDER_RASTER, ORDER_BLOCK2X2 = 0, 1
 GRAY_Q14, GRAY_Q15 = 0, 1
 K_GRAY, K_IALM_STATS, K_IALM_PASS, K_IALM_SMALL, K_FILTER, K_CCL, K_PROPS, K_COPY = range(8)
@@ -23,6 +26,10 @@ c_i32p = ctypes.POINTER(ctypes.c_int32)
 
 class SwkError(RuntimeError):
     pass
+
+
+class StaleBatch(SwkError):
+    """What a batch left on the device has been overwritten by a later call on the same context."""
 
 
 class Params(ctypes.Structure):
@@ -57,7 +64,8 @@ class Output(ctypes.Structure):
                 ("gray", ctypes.c_void_p), ("rpca", ctypes.c_void_p), ("bilateral", ctypes.c_void_p),
                 ("thresh", ctypes.c_void_p), ("opened", ctypes.c_void_p), ("labels", ctypes.c_void_p),
                 ("A", ctypes.c_void_p), ("E", ctypes.c_void_p),
-                ("iters", ctypes.c_void_p), ("nseg", ctypes.c_void_p), ("segs", ctypes.c_void_p)]
+                ("iters", ctypes.c_void_p), ("nseg", ctypes.c_void_p), ("segs", ctypes.c_void_p),
+                ("planes_on_device", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 _lib = None
@@ -95,8 +103,12 @@ _SIGS = {
     "swk_nhwc_conv3x3_winograd_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p] + [ctypes.c_int32] * 6),
     "swk_winograd_f2x2_3x3_weights": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_nhwc_maxpool3s2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
-    "swk_segment_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "swk_segment_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_segment_inputs_last": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_device_alloc": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "swk_device_free": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_device_read": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "swk_classifier_input_window": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_track_costs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_lsap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_median_blur_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -104,7 +116,7 @@ _SIGS = {
     "swk_canny_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_dilate_up_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "swk_roi_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
-    "swk_pinned_alloc": (ctypes.c_int32, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "swk_pinned_alloc": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     "swk_pinned_free": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -112,7 +124,6 @@ _SIGS = {
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_pass_tuning": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
-    "swk_set_classifier_input_layout": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_method": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
@@ -157,7 +168,7 @@ def load():
                 fn = getattr(lib, name)          # AttributeError = ABI mismatch, let it surface
                 fn.restype = res
                 fn.argtypes = args
-            if lib.swk_abi_version() != 1:
+            if lib.swk_abi_version() != ABI_VERSION:
                 raise SwkError("libswk.so ABI version mismatch")
             _lib = lib
     return _lib
@@ -211,11 +222,57 @@ class Context:
             self._h = None
             raise SwkError("swk_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.device = device
+        self.generation = 0          # batches run on this context: what a batch left on the device is gone once it moves on
+        self._plane_pool = {}        # size -> free device buffers of that size (stage images kept on the GPU, see DevicePlanes)
 
     def close(self):
         if getattr(self, "_h", None):
+            for ptrs in self._plane_pool.values():
+                for p in ptrs:
+                    self._lib.swk_device_free(self._h, ctypes.c_void_p(p))
+            self._plane_pool = {}
             self._lib.swk_ctx_destroy(self._h)
             self._h = None
+
+    # ---- device memory the caller keeps (stage images that are only copied to the host when somebody reads them) ----
+    def device_alloc(self, nbytes):
+        ptr = ctypes.c_void_p()
+        self._check(self._lib.swk_device_alloc(self._h, int(nbytes), ctypes.byref(ptr)))
+        return ptr.value
+
+    def device_free(self, ptr):
+        if getattr(self, "_h", None) and ptr:
+            self._check(self._lib.swk_device_free(self._h, ctypes.c_void_p(ptr)))
+
+    def device_read(self, ptr, shape, dtype=np.uint8):
+        out = np.empty(shape, dtype)
+        self._check(self._lib.swk_device_read(self._h, ctypes.c_void_p(ptr), _ptr(out), out.nbytes))
+        return out
+
+    def staging(self, shape):
+        """A page-locked uint8 staging array of this shape, kept for the next call with the same shape (calls on a context are
+        synchronous: the upload out of it has finished when batch_run returns)."""
+        cache = self.__dict__.setdefault("_staging", {})
+        arr = cache.get(shape)
+        if arr is None:
+            if len(cache) >= 2:
+                cache.pop(next(iter(cache)))
+            arr = cache[shape] = pinned_empty(shape, np.uint8, device=self.device)
+        return arr
+
+    def take_planes(self, nbytes):
+        """A device buffer of nbytes from the context's free list (or a new one): see DevicePlanes."""
+        free = self._plane_pool.get(nbytes)
+        return free.pop() if free else self.device_alloc(nbytes)
+
+    def give_planes(self, ptr, nbytes, keep=4):
+        if not getattr(self, "_h", None):
+            return
+        free = self._plane_pool.setdefault(nbytes, [])
+        if len(free) < keep:
+            free.append(ptr)
+        else:
+            self.device_free(ptr)
 
     def __del__(self):
         try:
@@ -255,10 +312,6 @@ class Context:
 
     def set_pass_tuning(self, flags):
         self._check(self._lib.swk_set_pass_tuning(self._h, int(flags)))
-
-    def set_classifier_input_layout(self, channels_last):
-        """False: the network input is written as planes (NCHW); True: channels-last (include/swk.h)."""
-        self._check(self._lib.swk_set_classifier_input_layout(self._h, 1 if channels_last else 0))
 
     def set_sparse_speculation(self, factor):
         self._check(self._lib.swk_set_sparse_speculation(self._h, float(factor)))
@@ -304,16 +357,19 @@ class Context:
 
     # ---- hot path ----
     def batch_run_raw(self, inp, params, out):
+        self.generation += 1
         self._check(self._lib.swk_batch_run(self._h, ctypes.byref(inp), ctypes.byref(params), ctypes.byref(out)))
 
-    def batch_run(self, frames, nwin, n, crop=None, params=None, stages=("gray", "rpca", "bilateral", "thresh", "opened", "labels"),
-                  want_A=False, want_E=False, seg_cap=255):
+    def batch_run(self, frames, nwin, n, crop=None, params=None, stages=STAGES, want_A=False, want_E=False, seg_cap=255,
+                  device_stages=False):
         """Host-buffer convenience wrapper.
 
         frames: u8 array (nwin*n, H, W, 3) or (nwin*n, H, W), C-contiguous in the last two/three axes
         crop:   (x0, y0, Wc, Hc) inside each frame, or None for the whole frame
         Returns dict with the requested stage stacks (nwin*n, Hc, Wc) u8, 'iters' (nwin,),
         'nseg' (nwin*n,), 'segs' structured array (nwin*n, seg_cap), optionally 'A'/'E' (nwin, P, n).
+        device_stages=True: the stage stacks stay on the GPU -- res['planes'] is a DevicePlanes whose read(stage, frame)
+        copies one image to the host when somebody asks for it (swk_output.planes_on_device).
         """
         params = params or default_params()
         F = nwin * n
@@ -332,9 +388,15 @@ class Context:
                     x0=x0, y0=y0, frame_stride=frames.strides[0], row_stride=frames.strides[1])
         res = {}
         out = Output(mem=MEM_HOST, seg_cap=seg_cap)
-        for name in stages:
-            res[name] = np.empty((F, Hc, Wc), np.uint8)
-            setattr(out, name, res[name].ctypes.data)
+        if device_stages and stages:
+            planes = res["planes"] = DevicePlanes(self, tuple(stages), F, Hc, Wc)
+            out.planes_on_device = 1
+            for name in stages:
+                setattr(out, name, planes.pointer(name))
+        else:
+            for name in stages:
+                res[name] = np.empty((F, Hc, Wc), np.uint8)
+                setattr(out, name, res[name].ctypes.data)
         P = Hc * Wc
         if want_A:
             res["A"] = np.empty((nwin, P, n), np.float64)
@@ -408,10 +470,11 @@ class Context:
                                          label_order, _ptr(lab), _ptr(nc)))
         return (int(nc[0]), lab[0]) if single else (nc, lab)
 
-    def classifier_input(self, crops, mean, std, want_patches=False, net_ptr=None, pad=100):
+    def classifier_input(self, crops, mean, std, want_patches=False, net_ptr=None, pad=100, channels_last=False):
         """swk_classifier_input_window for a list of HxWx3 uint8 crops.  Returns (patches or None, net or None):
         net is a float32 host array (n, 3, S, S), S = 24 + 2 pad, unless net_ptr (a device pointer with room for
-        it) is given.  pad = 100 is the reference's full 224x224 input."""
+        it) is given.  pad = 100 is the reference's full 224x224 input.  channels_last: the network input is written
+        [S][S][3] per segment (a torch.channels_last tensor) instead of planes."""
         n = len(crops)
         flat = [np.ascontiguousarray(c, np.uint8).reshape(-1) for c in crops]
         sizes = np.array([f.size for f in flat], np.int64)
@@ -428,11 +491,12 @@ class Context:
         else:
             nptr, nmem = ctypes.c_void_p(net_ptr), MEM_DEVICE
         self._check(self._lib.swk_classifier_input_window(self._h, _ptr(packed), packed.size, _ptr(offsets), _ptr(hw), n,
-                                                          _ptr(m), _ptr(s), int(pad), _ptr(patches), nptr, nmem))
+                                                          _ptr(m), _ptr(s), int(pad), 1 if channels_last else 0, _ptr(patches), nptr,
+                                                          nmem))
         return patches, net
 
     def segment_inputs(self, inp, frame_hw, segs_ptr, nseg_ptr, seg_cap, mean, std, net_ptr, net_cap, first=0, pad=8,
-                       min_seg_size=(24, 24), seg_frame_ptr=None):
+                       min_seg_size=(24, 24), seg_frame_ptr=None, channels_last=False):
         """swk_segment_inputs: classifier inputs cut on the device from the frames (inp, device-resident BGR) and the
         region records of a batch_run with device outputs.  Returns (total segments in the batch, skipped boxes)."""
         m = np.asarray(mean, np.float32)
@@ -442,9 +506,30 @@ class Context:
         self._check(self._lib.swk_segment_inputs(self._h, ctypes.byref(inp), int(frame_hw[0]), int(frame_hw[1]),
                                                  ctypes.c_void_p(segs_ptr), ctypes.c_void_p(nseg_ptr), int(seg_cap),
                                                  int(min_seg_size[0]), int(min_seg_size[1]), _ptr(m), _ptr(s), int(pad),
-                                                 int(first), int(net_cap), ctypes.c_void_p(net_ptr),
+                                                 1 if channels_last else 0, int(first), int(net_cap), ctypes.c_void_p(net_ptr),
                                                  ctypes.c_void_p(seg_frame_ptr) if seg_frame_ptr else None,
                                                  ctypes.byref(total), ctypes.byref(skipped)))
+        return total.value, skipped.value
+
+    def segment_inputs_last(self, generation, mean, std, net_ptr, net_cap, first=0, pad=8, min_seg_size=(24, 24),
+                            seg_frame_ptr=None, channels_last=False):
+        """swk_segment_inputs_last: the same for the batch this context ran LAST (its own device copy of the frames, its own
+        region records).  generation = Context.generation right after that batch_run: raises StaleBatch when the context
+        has run another batch since (the buffers hold something else now).  Returns (total, skipped)."""
+        m = np.asarray(mean, np.float32)
+        s = np.asarray(std, np.float32)
+        total = ctypes.c_int32(0)
+        skipped = ctypes.c_int32(0)
+        with self._lock:                 # nothing may slip in between the generation test and the call
+            if generation != self.generation:
+                raise StaleBatch("the context has run another batch since")
+            rc = self._lib.swk_segment_inputs_last(self._h, int(min_seg_size[0]), int(min_seg_size[1]), _ptr(m), _ptr(s), int(pad),
+                                                   1 if channels_last else 0, int(first), int(net_cap), ctypes.c_void_p(net_ptr),
+                                                   ctypes.c_void_p(seg_frame_ptr) if seg_frame_ptr else None,
+                                                   ctypes.byref(total), ctypes.byref(skipped))
+            if rc == ERR_STALE:
+                raise StaleBatch("the context no longer holds that batch")
+            self._check(rc)
         return total.value, skipped.value
 
     def regionprops_u8(self, labels, seg_cap=255):
@@ -456,42 +541,95 @@ class Context:
         return (segs[0, :nseg[0]], int(nseg[0])) if single else (segs, nseg)
 
 
+class DevicePlanes:
+    """The u8 stage images of one batch_run kept on the GPU: one device buffer [stage][frame][Hc][Wc] taken from the
+    context's free list and handed back when the last reader is gone.  read(stage, frame) copies ONE image to the
+    host (swk_device_read).  The reference stores six images per frame (data_structures.py:183-208) and its counting
+    loop reads none of them."""
+
+    def __init__(self, ctx, stages, F, Hc, Wc):
+        self.ctx, self.stages, self.F, self.Hc, self.Wc = ctx, stages, F, Hc, Wc
+        self.plane = F * Hc * Wc
+        self.nbytes = (self.plane + 3) // 4 * 4 * len(stages)          # every stack starts on a dword
+        self.ptr = ctx.take_planes(self.nbytes)
+
+    def pointer(self, stage):
+        return self.ptr + self.stages.index(stage) * ((self.plane + 3) // 4 * 4)
+
+    def read(self, stage, frame):
+        return self.ctx.device_read(self.pointer(stage) + frame * self.Hc * self.Wc, (self.Hc, self.Wc))
+
+    def read_stack(self, stage):
+        return self.ctx.device_read(self.pointer(stage), (self.F, self.Hc, self.Wc))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.ctx.give_planes(self.ptr, self.nbytes)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
 def track_costs(prev_c, prev_hist0, prev_has_hist, curr_c):
     """swk_track_costs: (n_prev + n_curr)^2 float64 cost matrix (host-side, no GPU needed)."""
     n_prev, n_curr = len(prev_c), len(curr_c)
-    n = n_prev + n_curr
     pc = np.ascontiguousarray(prev_c, np.float64).reshape(n_prev, 2)
     ph = np.ascontiguousarray(prev_hist0, np.float64).reshape(n_prev, 2)
     hh = np.ascontiguousarray(prev_has_hist, np.uint8).reshape(n_prev)
     cc = np.ascontiguousarray(curr_c, np.float64).reshape(n_curr, 2)
+    packed = np.concatenate([pc.ravel(), ph.ravel(), cc.ravel()])
+    return track_costs_packed(packed, hh.tobytes(), n_prev, n_curr)
+
+
+def track_costs_packed(packed, has_hist, n_prev, n_curr):
+    """The same from ONE float64 array [prev centroids (n_prev, 2) | first-of-history centroids (n_prev, 2) | current centroids
+    (n_curr, 2)] and a bytes object of n_prev flags: the per-frame call of the tracker (two array objects per call instead of
+    nine -- at a few dozen segments the marshalling, not the arithmetic, is the cost)."""
+    n = n_prev + n_curr
     cost = np.empty((n, n), np.float64)
-    rc = load().swk_track_costs(_ptr(pc), _ptr(ph), _ptr(hh), _ptr(cc), n_prev, n_curr, _ptr(cost))
+    base = packed.ctypes.data
+    rc = _track_costs_fn()(base, base + 16 * n_prev, has_hist, base + 32 * n_prev, n_prev, n_curr, cost.ctypes.data)
     if rc:
         raise SwkError("swk_track_costs failed (%d)" % rc)
     return cost
 
 
+_fast = {}
+
+
+def _track_costs_fn():
+    fn = _fast.get("costs")
+    if fn is None:
+        fn = _fast["costs"] = load().swk_track_costs
+    return fn
+
+
 def lsap(cost):
     """swk_lsap: column assigned to every row (same result as scipy.optimize.linear_sum_assignment)."""
-    cost = np.ascontiguousarray(cost, np.float64)
+    if cost.dtype != np.float64 or not cost.flags.c_contiguous:
+        cost = np.ascontiguousarray(cost, np.float64)
     nr, nc = cost.shape
     out = np.empty(nr, np.int32)
-    rc = load().swk_lsap(_ptr(cost), nr, nc, _ptr(out))
+    fn = _fast.get("lsap")
+    if fn is None:
+        fn = _fast["lsap"] = load().swk_lsap
+    rc = fn(cost.ctypes.data, nr, nc, out.ctypes.data)
     if rc:
         raise SwkError("swk_lsap failed (%d)" % rc)
     return out
 
 
-def pinned_empty(shape, dtype=np.uint8):
-    """numpy array in page-locked host memory (swk_pinned_alloc): staging buffer for host -> device input, freed when the
-    array (and every view of it) is gone.  Falls back to ordinary memory when pinning fails: pinning is an
-    optimisation, never a requirement."""
+def pinned_empty(shape, dtype=np.uint8, device=0):
+    """numpy array in page-locked host memory (swk_pinned_alloc on `device`): staging buffer for host -> device input,
+    freed when the array (and every view of it) is gone.  Falls back to ordinary memory when pinning fails: pinning is
+    an optimisation, never a requirement."""
     import weakref
     count = int(np.prod(shape))
     nbytes = max(count * np.dtype(dtype).itemsize, 1)
     lib = load()
     ptr = ctypes.c_void_p()
-    if lib.swk_pinned_alloc(nbytes, ctypes.byref(ptr)) != 0 or not ptr.value:
+    if lib.swk_pinned_alloc(int(device), nbytes, ctypes.byref(ptr)) != 0 or not ptr.value:
         return np.empty(shape, dtype)
     buf = (ctypes.c_uint8 * nbytes).from_address(ptr.value)      # numpy keeps this object alive as .base
     weakref.finalize(buf, lib.swk_pinned_free, ctypes.c_void_p(ptr.value))

@@ -162,7 +162,6 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
-extern int g_wino_nbw1;
 int g_conv1x1_ring = 0;          // A/B knob: 0 = 16-wave workgroups, column blocks of the wide expands split over two waves; 1 = the
                                  // first layout (8 waves, every wave all column blocks, activation ring as deep as fits)
 
@@ -225,7 +224,6 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value)
 {
     if (knob == 0 && (value == 0 || value == 1)) { swk::g_conv1x1_ring = value; return SWK_OK; }
-    if (knob == 1 && (value == 0 || value == 1)) { swk::g_wino_nbw1 = value; return SWK_OK; }
     return SWK_ERR_ARG;
 }
 

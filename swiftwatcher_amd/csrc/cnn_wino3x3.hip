@@ -18,7 +18,7 @@
 //     NBW = 1 is the default: 128 registers, four waves per SIMD (8-wave workgroups for 64 -> 256, 4-wave ones for 32 -> 128;
 //     48 -> 192 has six column blocks and runs as ONE 12-wave workgroup per CU, three waves on every SIMD -- two 6-wave
 //     workgroups do not become co-resident and leave two SIMDs half empty).  NBW = 2 (226 registers, two waves per SIMD)
-//     is kept behind swk_set_cnn_tuning(1, 0): 6 % slower on 64 -> 256, 15 % on 32 -> 128.
+//     measured 6 % slower on 64 -> 256 and 15 % on 32 -> 128 (round 2) and is no longer instantiated.
 //   * V_p = B^T d B restricted to position p is a signed sum of FOUR patch pixels.  The workgroup forms V_p for its tiles
 //     once (NBW (tile, 4-channel) items per thread: 4 float4 loads, 3 fmas per component), transposes it into LDS as
 //     [channel][tile] -- the matrix cores' pixel operand -- double buffered: position p + 1 is staged while p multiplies
@@ -47,7 +47,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // Diagnostic build only (-DSWK_WINO_STAMP, tools/wino_stamp.py): s_memtime brackets around the parts of a phase, summed per wave
 // and stored to g_wino_stamp[wave][5] by lane 0.  Its fences forbid overlaps the real kernel has: read the shares, not the length.
 #ifdef SWK_WINO_STAMP
-int g_launch_error = 0;          // the diagnostic library is this file alone
+std::atomic<int> g_launch_error{0};          // the diagnostic library is this file alone
 __device__ unsigned long long *g_wino_stamp;
 #define SWK_STAMP(k)                                                                                 \
     do {                                                                                             \
@@ -337,9 +337,8 @@ __global__ __launch_bounds__(64 * (NBLK / NBW) * TGN, WPS) void k_wino3x3_relu_p
 #endif
 }
 
-int g_wino_nbw1 = 1;          // A/B knob (swk_set_cnn_tuning 1): one column block per wave (three or four waves per SIMD) or two
-// column blocks per wave of the configuration a shape runs on (the filter layout depends on it)
-static int wino_nbw(int, int) { return g_wino_nbw1 ? 1 : 2; }
+// column blocks per wave of the configuration a shape runs on (the filter layout depends on it): one for every Fire shape
+static int wino_nbw(int, int) { return 1; }
 // private per-wave filter slices (their own layout): the 64 -> 256 configuration with one column block per wave
 static bool wino_priv(int cin, int cout) { return cin == 64 && cout == 256 && wino_nbw(cin, cout) == 1; }
 
@@ -424,11 +423,10 @@ int32_t swk_nhwc_conv3x3_winograd_bias_relu_place(void *stream, const float *src
     hipStream_t s = (hipStream_t)stream;
     // the squeeze ratio of SqueezeNet's Fire modules: 8 input channels per 32 output channels
 #define SWK_W3_ARGS s, src, n, t, weight_w, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off
-    const bool one = wino_nbw(cin, cout) == 1;
-    if (cin == 16 && cout == 64 && one) return launch_wino3x3<2, 1, 2, 1, 4, false>(SWK_W3_ARGS);
-    if (cin == 32 && cout == 128) return one ? launch_wino3x3<4, 1, 1, 1, 4, false>(SWK_W3_ARGS) : launch_wino3x3<4, 2, 2, 2, 2, false>(SWK_W3_ARGS);
-    if (cin == 48 && cout == 192) return one ? launch_wino3x3<6, 1, 2, 3, 3, false>(SWK_W3_ARGS) : launch_wino3x3<6, 2, 2, 3, 2, false>(SWK_W3_ARGS);
-    if (cin == 64 && cout == 256) return one ? launch_wino3x3<8, 1, 1, 1, 4, true>(SWK_W3_ARGS) : launch_wino3x3<8, 2, 1, 2, 2, false>(SWK_W3_ARGS);
+    if (cin == 16 && cout == 64) return launch_wino3x3<2, 1, 2, 1, 4, false>(SWK_W3_ARGS);
+    if (cin == 32 && cout == 128) return launch_wino3x3<4, 1, 1, 1, 4, false>(SWK_W3_ARGS);
+    if (cin == 48 && cout == 192) return launch_wino3x3<6, 1, 2, 3, 3, false>(SWK_W3_ARGS);
+    if (cin == 64 && cout == 256) return launch_wino3x3<8, 1, 1, 1, 4, true>(SWK_W3_ARGS);
 #undef SWK_W3_ARGS
     return SWK_ERR_ARG;
 }

@@ -5,12 +5,13 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
 using namespace swk;
 
-namespace swk { int g_launch_error = 0; }
+namespace swk { std::atomic<int> g_launch_error{0}; }
 
 namespace {
 
@@ -51,7 +52,6 @@ struct swk_ctx {
     int64_t redo_batches = 0;
     int last_eig_sweeps = 0;       // largest IalmWin::sweeps of the last batch (Newton-Schulz iterations, or 100 + Jacobi sweeps)
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
-    int cls_nhwc = 0;              // classifier-input kernels write channels-last ([y][x][c]) instead of planes
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 256.0;      // M-state pass: ||Z|| every other iteration while above 256 x tol (<= 0: every iteration)
@@ -68,6 +68,16 @@ struct swk_ctx {
     int last_nwin = 0;
     int64_t pstride = 0;                 // plane pitch of the A/Y/E workspaces of the last IALM run
     int fpad = 0;                        // planes per window in them
+    // what the last swk_batch_run left on the device for swk_segment_inputs_last: its frames (SL_ROI copy of a host input,
+    // or the caller's device frames) and region records; valid until a call reuses those buffers
+    struct LastBatch {
+        bool valid = false;
+        const uint8_t *frames = nullptr;
+        int64_t fs = 0, rs = 0;
+        int nwin = 0, n = 0, Hc = 0, Wc = 0, x0 = 0, y0 = 0, frame_h = 0, frame_w = 0, cap = 0;
+        const swk_segment *segs = nullptr;
+        const int32_t *nseg = nullptr;
+    } last;
 };
 
 namespace {
@@ -189,10 +199,8 @@ int sync(swk_ctx *ctx)
     for (int g = 0; g < ctx->ngroups_ready; ++g) HIPCHK(ctx, hipStreamSynchronize(ctx->gstream[g]));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
-    if (g_launch_error) {          // a launcher could not set a kernel attribute or start a kernel
-        const hipError_t e = (hipError_t)g_launch_error;
-        g_launch_error = 0;
-        HIPCHK(ctx, e);
+    if (const int le = g_launch_error.exchange(0)) {          // a launcher could not set a kernel attribute or start a kernel
+        HIPCHK(ctx, (hipError_t)le);
     }
     drain_prof(ctx);
     return SWK_OK;
@@ -442,6 +450,36 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     return SWK_OK;
 }
 
+int segment_inputs_impl(swk_ctx *ctx, const uint8_t *frames, int64_t fs, int64_t rs, int F, int x0, int y0, int frame_h, int frame_w,
+                        const swk_segment *segs, const int32_t *nseg, int seg_cap, int min_h, int min_w, const float *mean,
+                        const float *std_, int pad, bool nhwc, int first, int net_cap, float *net, int32_t *seg_frame, int32_t *total,
+                        int32_t *skipped)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int32_t *doffs;
+    NEED(ctx, SL_SEGOFFS, ((size_t)F + 2) * 4, doffs);           // [F+1] prefix sums, then the skipped-box counter
+    int32_t *dskip = doffs + F + 1;
+    HIPCHK(ctx, hipMemsetAsync(dskip, 0, 4, s));
+    launch_segment_prefix(s, nseg, F, seg_cap, doffs);
+    int32_t tot = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&tot, doffs + F, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    *total = tot;
+    if (skipped) *skipped = 0;
+    int count = tot - first;
+    if (count > net_cap) count = net_cap;
+    if (count < 1) return SWK_OK;
+    launch_segment_inputs(s, frames, fs, rs, frame_h, frame_w, x0, y0, segs, doffs, F, seg_cap,
+                          min_h, min_w, first, count, net, seg_frame, pad, nhwc, mean, std_, dskip);
+    int32_t sk = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&sk, dskip, 4, hipMemcpyDeviceToHost, s));
+    int rc = sync(ctx);
+    if (rc) return rc;
+    if (skipped) *skipped = sk;
+    return SWK_OK;
+}
+
 int copy_out(swk_ctx *ctx, void *dst, const void *src, size_t bytes, int mem)
 {
     if (!dst || dst == src) return SWK_OK;
@@ -572,11 +610,14 @@ int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 
 // Page-locked host memory for the caller's staging buffers: a host -> device copy out of it is one DMA instead of a
 // driver-side staging copy plus a DMA (the FrameQueue drop-in stacks a window's crops into such a buffer).
-int32_t swk_pinned_alloc(int64_t bytes, void **out)
+int32_t swk_pinned_alloc(int32_t device, int64_t bytes, void **out)
 {
-    if (!out || bytes < 1) return SWK_ERR_ARG;
+    if (!out || bytes < 1 || device < 0) return SWK_ERR_ARG;
     *out = nullptr;
-    if (hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return SWK_ERR_NOMEM; }
+    // on the GPU the buffer feeds (a thread that has not chosen a device would otherwise open a context on GPU 0); portable: every
+    // context of the process may copy out of it
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return SWK_ERR_ARG; }
+    if (hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return SWK_ERR_NOMEM; }
     return SWK_OK;
 }
 
@@ -586,10 +627,31 @@ int32_t swk_pinned_free(void *p)
     return hipHostFree(p) == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
-int32_t swk_set_classifier_input_layout(swk_ctx *ctx, int32_t channels_last)
+int32_t swk_device_alloc(swk_ctx *ctx, int64_t bytes, void **out)
 {
-    if (!ctx || (channels_last != 0 && channels_last != 1)) return SWK_ERR_ARG;
-    ctx->cls_nhwc = channels_last;
+    if (!ctx || !out || bytes < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(out, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(ctx, SWK_ERR_NOMEM, "hipMalloc failed"); }
+    return SWK_OK;
+}
+
+int32_t swk_device_free(swk_ctx *ctx, void *p)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    if (!p) return SWK_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(p));
+    return SWK_OK;
+}
+
+int32_t swk_device_read(swk_ctx *ctx, const void *src_device, void *dst_host, int64_t bytes)
+{
+    if (!ctx || !src_device || !dst_host || bytes < 1) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SWK_OK;
 }
 
@@ -683,7 +745,9 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
     const int F = in->nwin * in->n, H = in->Hc, W = in->Wc, P = H * W;
     const size_t plane = (size_t)F * P;
     const bool dev_out = out->mem == SWK_MEM_DEVICE;
+    const bool dev_planes = dev_out || out->planes_on_device != 0;       // the six u8 stage images stay on the device
     int rc;
+    ctx->last.valid = false;
 
     // ---- input ----
     const uint8_t *dframes = in->frames;
@@ -693,10 +757,19 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         uint8_t *roi;
         NEED(ctx, SL_ROI, plane * in->channels, roi);
         Timed t(ctx, SWK_K_COPY);
+        bool whole = false;
         const size_t rowb = (size_t)W * in->channels;
         if (x0 == 0 && (size_t)rs == rowb && fs == (int64_t)H * rs) {
             // pre-cropped, densely packed ROI frames: one copy for the whole batch
             HIPCHK(ctx, hipMemcpyAsync(roi, in->frames + (int64_t)y0 * rs, plane * in->channels, hipMemcpyHostToDevice, s));
+        } else if (rs >= (int64_t)(x0 + W) * in->channels && rs % in->channels == 0 && fs % rs == 0 && fs >= (int64_t)(y0 + H) * rs &&
+                   (size_t)F * (size_t)fs <= 2 * plane * in->channels) {
+            // ROI frames with a margin around them (FrameQueue stages the crop plus the half minimum segment size, so that
+            // segment boxes can grow into it like they grow into the full frame, image_filtering.py:338-369): the whole
+            // buffer in one copy; the kernels read the ROI at (x0, y0) of the device copy
+            NEED(ctx, SL_ROI, (size_t)F * (size_t)fs, roi);
+            HIPCHK(ctx, hipMemcpyAsync(roi, in->frames, (size_t)F * (size_t)fs, hipMemcpyHostToDevice, s));
+            whole = true;
         } else if (x0 == 0 && (size_t)rs == rowb) {
             for (int f = 0; f < F; ++f)                    // full-width rows: one contiguous block per frame
                 HIPCHK(ctx, hipMemcpyAsync(roi + (size_t)f * P * in->channels, in->frames + (int64_t)f * fs + (int64_t)y0 * rs,
@@ -707,19 +780,20 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
                                              in->frames + (int64_t)f * fs + (int64_t)y0 * rs + (int64_t)x0 * in->channels, (size_t)rs,
                                              rowb, H, hipMemcpyHostToDevice, s));
         }
-        dframes = roi; fs = (int64_t)P * in->channels; rs = (int64_t)rowb; x0 = 0; y0 = 0;
+        dframes = roi;
+        if (!whole) { fs = (int64_t)P * in->channels; rs = (int64_t)rowb; x0 = 0; y0 = 0; }
     }
     // ---- stage buffers (caller's device buffers are written in place) ----
     uint8_t *dX, *dS, *dBil = nullptr, *dThr = nullptr, *dOpen, *dLab;
     // (a gray plane whose size is not a whole number of dwords stays in the library's padded buffer: k_gram_u8 reads
     // it in dwords; the caller's copy is made at the end)
-    const bool gray_in_place = dev_out && out->gray && (plane & 3) == 0;
+    const bool gray_in_place = dev_planes && out->gray && (plane & 3) == 0;
     if (gray_in_place) dX = out->gray; else NEED(ctx, SL_X, plane + 4, dX);
-    if (dev_out && out->rpca) dS = out->rpca; else NEED(ctx, SL_S, plane, dS);
-    if (out->bilateral) { if (dev_out) dBil = out->bilateral; else NEED(ctx, SL_BIL, plane, dBil); }
-    if (out->thresh) { if (dev_out) dThr = out->thresh; else NEED(ctx, SL_THR, plane, dThr); }
-    if (dev_out && out->opened) dOpen = out->opened; else NEED(ctx, SL_OPEN, plane, dOpen);
-    if (dev_out && out->labels) dLab = out->labels; else NEED(ctx, SL_LAB8, plane, dLab);
+    if (dev_planes && out->rpca) dS = out->rpca; else NEED(ctx, SL_S, plane, dS);
+    if (out->bilateral) { if (dev_planes) dBil = out->bilateral; else NEED(ctx, SL_BIL, plane, dBil); }
+    if (out->thresh) { if (dev_planes) dThr = out->thresh; else NEED(ctx, SL_THR, plane, dThr); }
+    if (dev_planes && out->opened) dOpen = out->opened; else NEED(ctx, SL_OPEN, plane, dOpen);
+    if (dev_planes && out->labels) dLab = out->labels; else NEED(ctx, SL_LAB8, plane, dLab);
 
     { Timed t(ctx, SWK_K_GRAY); launch_gray(s, dframes, in->channels, fs, rs, x0, y0, F, H, W, p->gray_mode, dX); }
 
@@ -771,8 +845,8 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
             if (!dev_out) { rc = copy_out(ctx, dst, pn, elems * 8, out->mem); if (rc) return rc; HIPCHK(ctx, hipStreamSynchronize(s)); }
         }
     }
-    if (dev_out && out->gray && !gray_in_place) { rc = copy_out(ctx, out->gray, dX, plane, out->mem); if (rc) return rc; }
-    if (!dev_out) {
+    if (dev_planes && out->gray && !gray_in_place) { rc = copy_out(ctx, out->gray, dX, plane, SWK_MEM_DEVICE); if (rc) return rc; }
+    if (!dev_planes) {
         Timed t(ctx, SWK_K_COPY);
         rc = copy_out(ctx, out->gray, dX, plane, out->mem); if (rc) return rc;
         rc = copy_out(ctx, out->rpca, dS, plane, out->mem); if (rc) return rc;
@@ -783,6 +857,14 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
     }
     rc = sync(ctx);
     if (rc) return rc;
+    if (out->segs && in->channels == 3) {
+        swk_ctx::LastBatch &lb = ctx->last;
+        lb.frames = dframes; lb.fs = fs; lb.rs = rs;
+        lb.nwin = in->nwin; lb.n = in->n; lb.Hc = H; lb.Wc = W; lb.x0 = x0; lb.y0 = y0;
+        lb.frame_h = (int)(fs / rs); lb.frame_w = (int)(rs / 3);
+        lb.segs = dsegs; lb.nseg = dnseg; lb.cap = cap;
+        lb.valid = true;
+    }
     return gather_iters(ctx, dev_out ? nullptr : out->iters, dev_out ? out->iters : nullptr);
 }
 
@@ -913,6 +995,7 @@ int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, i
     if (!ctx || !labels || !segs || !nseg || count < 1 || H < 1 || W < 1 || seg_cap < 1 || seg_cap > 255)
         return fail(ctx, SWK_ERR_ARG, "bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->last.valid = false;          // SL_SEGS / SL_NSEG are about to be reused
     const size_t px = (size_t)count * H * W;
     uint8_t *din; swk_segment *dsegs; int32_t *dnseg;
     NEED(ctx, SL_TMP_IN, px, din);
@@ -931,10 +1014,10 @@ int32_t swk_regionprops_u8(swk_ctx *ctx, const uint8_t *labels, int32_t count, i
 
 int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
                                     const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
-                                    int32_t pad, uint8_t *patches, float *net, int32_t net_mem)
+                                    int32_t pad, int32_t channels_last, uint8_t *patches, float *net, int32_t net_mem)
 {
     if (!ctx || !crops || !offsets || !hw || !mean || !std_ || nseg < 1 || crops_bytes < 1 || (!patches && !net) ||
-        pad < 0 || pad > 100)
+        pad < 0 || pad > 100 || (channels_last != 0 && channels_last != 1))
         return fail(ctx, SWK_ERR_ARG, "bad argument");
     for (int i = 0; i < nseg; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
@@ -954,7 +1037,7 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
     const size_t side = 24 + 2 * (size_t)pad;
     const size_t net_bytes = (size_t)nseg * 3 * side * side * sizeof(float);
     if (net) { if (net_mem == SWK_MEM_DEVICE) dnet = net; else NEED(ctx, SL_CL_NET, net_bytes, dnet); }
-    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, pad, ctx->cls_nhwc != 0, mean, std_);
+    launch_classifier_input(s, dcrops, doffs, dhw, nseg, dpatch, dnet, pad, channels_last != 0, mean, std_);
     if (patches) HIPCHK(ctx, hipMemcpyAsync(patches, dpatch, (size_t)nseg * 24 * 24 * 3, hipMemcpyDeviceToHost, s));
     if (net && net_mem != SWK_MEM_DEVICE) HIPCHK(ctx, hipMemcpyAsync(net, dnet, net_bytes, hipMemcpyDeviceToHost, s));
     return sync(ctx);
@@ -962,7 +1045,7 @@ int32_t swk_classifier_input_window(swk_ctx *ctx, const uint8_t *crops, int64_t 
 
 int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, int32_t frame_w,
                            const swk_segment *segs, const int32_t *nseg, int32_t seg_cap, int32_t min_h, int32_t min_w,
-                           const float mean[3], const float std_[3], int32_t pad, int32_t first, int32_t net_cap,
+                           const float mean[3], const float std_[3], int32_t pad, int32_t channels_last, int32_t first, int32_t net_cap,
                            float *net, int32_t *seg_frame, int32_t *total, int32_t *skipped)
 {
     if (!ctx || !in || !in->frames || !segs || !nseg || !mean || !std_ || !net || !total)
@@ -970,41 +1053,33 @@ int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, i
     if (in->mem != SWK_MEM_DEVICE || in->channels != 3) return fail(ctx, SWK_ERR_ARG, "segment inputs are cut from device-resident BGR frames");
     const int64_t F64 = (int64_t)in->nwin * in->n;
     if (in->nwin < 1 || in->n < 1 || F64 > (1 << 24) || seg_cap < 1 || pad < 0 || pad > 100 || first < 0 || net_cap < 1 ||
+        (channels_last != 0 && channels_last != 1) ||
         frame_h < 1 || frame_w < 1 || min_h < 1 || min_w < 1 || min_h > 512 || min_w > 512 ||
         in->x0 < 0 || in->y0 < 0 || in->x0 + in->Wc > frame_w || in->y0 + in->Hc > frame_h ||
         in->row_stride < (int64_t)frame_w * 3 || in->frame_stride < in->row_stride * frame_h)
         return fail(ctx, SWK_ERR_ARG, "bad geometry");
-    const int F = (int)F64;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    int32_t *doffs;
-    NEED(ctx, SL_SEGOFFS, ((size_t)F + 2) * 4, doffs);           // [F+1] prefix sums, then the skipped-box counter
-    int32_t *dskip = doffs + F + 1;
-    HIPCHK(ctx, hipMemsetAsync(dskip, 0, 4, s));
-    launch_segment_prefix(s, nseg, F, seg_cap, doffs);
-    int32_t tot = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&tot, doffs + F, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    *total = tot;
-    if (skipped) *skipped = 0;
-    int count = tot - first;
-    if (count > net_cap) count = net_cap;
-    if (count < 1) return SWK_OK;
-    launch_segment_inputs(s, in->frames, in->frame_stride, in->row_stride, frame_h, frame_w, in->x0, in->y0, segs, doffs, F, seg_cap,
-                          min_h, min_w, first, count, net, seg_frame, pad, ctx->cls_nhwc != 0, mean, std_, dskip);
-    int32_t sk = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&sk, dskip, 4, hipMemcpyDeviceToHost, s));
-    int rc = sync(ctx);
-    if (rc) return rc;
-    if (skipped) *skipped = sk;
-    return SWK_OK;
+    return segment_inputs_impl(ctx, in->frames, in->frame_stride, in->row_stride, (int)F64, in->x0, in->y0, frame_h, frame_w, segs, nseg,
+                               seg_cap, min_h, min_w, mean, std_, pad, channels_last != 0, first, net_cap, net, seg_frame, total, skipped);
+}
+
+int32_t swk_segment_inputs_last(swk_ctx *ctx, int32_t min_h, int32_t min_w, const float mean[3], const float std_[3], int32_t pad,
+                                int32_t channels_last, int32_t first, int32_t net_cap, float *net, int32_t *seg_frame, int32_t *total,
+                                int32_t *skipped)
+{
+    if (!ctx || !mean || !std_ || !net || !total || pad < 0 || pad > 100 || first < 0 || net_cap < 1 ||
+        (channels_last != 0 && channels_last != 1) || min_h < 1 || min_w < 1 || min_h > 512 || min_w > 512)
+        return fail(ctx, SWK_ERR_ARG, "bad argument");
+    const swk_ctx::LastBatch &lb = ctx->last;
+    if (!lb.valid) return fail(ctx, SWK_ERR_STALE, "no batch with BGR frames and region records is held by the context any more");
+    return segment_inputs_impl(ctx, lb.frames, lb.fs, lb.rs, lb.nwin * lb.n, lb.x0, lb.y0, lb.frame_h, lb.frame_w, lb.segs, lb.nseg, lb.cap,
+                               min_h, min_w, mean, std_, pad, channels_last != 0, first, net_cap, net, seg_frame, total, skipped);
 }
 
 int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,
                              const int32_t *hw, int32_t nseg, const float mean[3], const float std_[3],
                              uint8_t *patches, float *net, int32_t net_mem)
 {
-    return swk_classifier_input_window(ctx, crops, crops_bytes, offsets, hw, nseg, mean, std_, 100, patches, net, net_mem);
+    return swk_classifier_input_window(ctx, crops, crops_bytes, offsets, hw, nseg, mean, std_, 100, 0, patches, net, net_mem);
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "swk.h"
 
 namespace swk {
@@ -11,8 +12,8 @@ constexpr int kMaxN = 64;          // frames per window supported by the IALM ke
 // Kernels that take more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute
 // belongs to the (kernel, device) pair: `mask` (one static per kernel instantiation) keeps a bit per device it has been
 // set on, so a second context on another device of the same process gets it too.  A failure is parked in
-// g_launch_error and surfaces at the context's next sync().
-extern int g_launch_error;
+// g_launch_error (one atomic for the process: launchers do not know a context) and surfaces at the next sync() of a context.
+extern std::atomic<int> g_launch_error;
 inline bool ensure_dyn_lds(const void *fn, size_t bytes, unsigned long long &mask)
 {
     int dev = 0;

@@ -3,7 +3,17 @@
 run the whole window as ONE call into the HIP library (swk_batch_run) instead of six Python
 list comprehensions over OpenCV / SciPy / scikit-image.
 
+What a window leaves on the GPU stays there until somebody asks for it:
+  * the six stage images of every frame (:183-208 stores them, the counting loop reads none) are values of
+    Frame.processed_frames that copy ONE image to the host on first read (_LazyStages over _lib.DevicePlanes);
+  * the ROI frames (with a margin of half the minimum segment size, so that segment boxes grow into it exactly like
+    they grow into the full frame, image_filtering.py:338-369) and the region records: SegmentClassifier scores ALL
+    segments of the window in one batch at the window's first classifier(frame.segments) call (__main__.py:84-85) and
+    answers the following calls from that table (WindowBatch);
+  * Segment.segment_image is cut (a view of the full frame, like the reference's) when it is first read.
+
 Not mirrored: Frame.export_segments (:65-113, PNG debug output, cv2.imwrite)."""
+import weakref
 from collections import OrderedDict, deque
 
 import numpy as np
@@ -18,18 +28,44 @@ STAGE_KEYS = OrderedDict([("gray", "grayscale"), ("rpca", "RPCA"), ("bilateral",
 class Segment:
     """data_structures.py:16-30.  The reference copies every public regionprops attribute
     (about 9 ms per segment); only label/bbox/centroid/area are ever read downstream
-    (segment_tracking.py:139-222, segment_classification.py:30,42), so only those exist here."""
+    (segment_tracking.py:139-222, segment_classification.py:30,42), so only those exist here.
+    segment_image may be handed in as a zero-argument callable: it is then cut when first read."""
 
     def __init__(self, regionprops, frame_number, timestamp, segment_image):
         self.parent_frame_number = frame_number
         self.parent_timestamp = timestamp
-        self.segment_image = segment_image
+        self._image = segment_image
         self.segment_history = []
         self.status = None
         self.label = regionprops.label
         self.bbox = regionprops.bbox
         self.centroid = regionprops.centroid
         self.area = regionprops.area
+
+    @property
+    def segment_image(self):
+        im = self._image
+        if callable(im):
+            im = self._image = im()
+        return im
+
+    @segment_image.setter
+    def segment_image(self, value):
+        self._image = value
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(tracker.detected_events) (__main__.py:100): plain data only -- the image is resolved, the link to the
+        window's device-side state is dropped."""
+        import copy
+        new = Segment.__new__(Segment)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_batch", "_index"):
+                continue
+            if k == "_image":
+                v = self.segment_image
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 class _LazyStages(OrderedDict):
@@ -42,6 +78,9 @@ class _LazyStages(OrderedDict):
             v = v()
             OrderedDict.__setitem__(self, key, v)
         return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
 
     def values(self):
         return [self[k] for k in self.keys()]
@@ -77,9 +116,53 @@ class Frame:
                          for rp, seg in zip(regionprops_list, segment_images)]
 
 
+class WindowBatch:
+    """What one segment_queue call left on the device for the classifier: the window's frames and region records, held by
+    the library context until its next batch.  Segment k of the batch (frames in queue order, ascending label) carries
+    (_batch, _index = k); SegmentClassifier asks predictions(classifier) for the whole table once per window.  Returns None
+    when the context has moved on (the caller then classifies from the segments' images, as before)."""
+
+    def __init__(self, ctx, generation, total, min_seg_size, queue=None):
+        self.ctx, self.generation, self.total, self.min_seg_size = ctx, generation, total, tuple(min_seg_size)
+        self.queue = weakref.ref(queue) if queue is not None else None
+        self._tables = {}          # id(classifier) -> numpy int array (total,) of predicted classes, or a pending device tensor
+        self.used = False
+
+    def alive(self):
+        return self.generation == self.ctx.generation
+
+    def launch(self, classifier):
+        """Start scoring the window's segments on the GPU without waiting for the result."""
+        key = id(classifier)
+        if key in self._tables or not self.alive() or self.total == 0:
+            return
+        try:
+            self._tables[key] = classifier.predict_last_batch(self.ctx, self.generation, self.total, self.min_seg_size)
+        except _lib.StaleBatch:
+            pass
+
+    def predictions(self, classifier):
+        key = id(classifier)
+        if key not in self._tables:
+            self.launch(classifier)
+        table = self._tables.get(key)
+        if table is None:
+            return None
+        if not isinstance(table, np.ndarray):
+            table = self._tables[key] = table.cpu().numpy()          # waits for the forward that launch() started
+        self.used = True
+        q = self.queue() if self.queue is not None else None
+        if q is not None:
+            q._classifier_hint = weakref.ref(classifier)             # the next window is scored as soon as it is segmented
+        return table
+
+
 class FrameQueue(deque):
     """data_structures.py:116-217.  Index 0 is the newest frame (appendleft, :134); RPCA column j
-    is queue index j (image_filtering.py:234-237)."""
+    is queue index j (image_filtering.py:234-237).
+
+    keep_stages=True (the default, like the reference) makes the six stage images available under
+    Frame.processed_frames; they stay on the GPU until read.  keep_stages=False does not produce them at all."""
 
     def __init__(self, queue_size=21, device=0, params=None, keep_stages=True):
         deque.__init__(self, maxlen=queue_size)
@@ -90,6 +173,8 @@ class FrameQueue(deque):
         self.keep_stages = keep_stages
         self.last_iters = None
         self._staging = None
+        self._classifier_hint = None      # weakref to the classifier that asked for the last window's scores
+        self._last_batch = None
 
     # ---- container behaviour (reference :126-169): newest frame at index 0, oldest popped first ----
     def is_empty(self):
@@ -136,65 +221,107 @@ class FrameQueue(deque):
             crop = crops[pos]
             self[pos].processed_frames["grayscale"] = (lambda c=crop: img.convert_grayscale(c))
 
-    def _stack_crops(self):
-        crops = self.get_processed_queue("crop")
-        shape = (len(crops),) + crops[0].shape
+    def _stage_window(self, min_seg_size, crop_region):
+        """The window's ROI crops plus a margin of half the minimum segment size (clipped to the frame), stacked in
+        page-locked memory: (staging array (n, Hm, Wm, 3), (x, y) of the ROI inside it, ROI (Hc, Wc))."""
+        frames = self.get_queue()
+        (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(frames[0].shape, crop_region, min_seg_size)
+        shape = (len(frames), yb - ya, xb - xa) + frames[0].shape[2:]
         if self._staging is None or self._staging.shape != shape:
-            self._staging = _lib.pinned_empty(shape, np.uint8)      # page-locked: the upload is one DMA
-        for i, c in enumerate(crops):
-            self._staging[i] = c
-        return self._staging
+            self._staging = _lib.pinned_empty(shape, np.uint8, device=self.device)      # page-locked: the upload is one DMA
+        for i, f in enumerate(frames):
+            self._staging[i] = f[ya:yb, xa:xb]
+        return self._staging, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
 
     def segment_queue(self, min_seg_size, crop_region):
         """:187-217: RPCA -> bilateral -> threshold -> opening -> CCL -> region properties ->
         segment crops, one swk_batch_run for the whole window."""
         if "crop" not in self[0].processed_frames:
             raise RuntimeError("preprocess_queue must run before segment_queue")
-        roi = self._stack_crops()
-        n = roi.shape[0]
+        stack, (rx, ry), (Hc, Wc) = self._stage_window(min_seg_size, crop_region)
+        n = stack.shape[0]
         ctx = _lib.default_context(self.device)
         stages = tuple(STAGE_KEYS) if self.keep_stages else ()
-        res = ctx.batch_run(roi, 1, n, params=self.params, stages=stages)
+        res = ctx.batch_run(stack, 1, n, crop=(rx, ry, Wc, Hc), params=self.params, stages=stages, device_stages=True)
+        generation = ctx.generation
         self.last_iters = int(res["iters"][0])
-        for key, name in STAGE_KEYS.items():
-            if key in res:
-                self.store_processed_queue([res[key][i] for i in range(n)], name)
-        if np.any(res["nseg"] > res["segs"].shape[1]):
+        nseg = res["nseg"]
+        if np.any(nseg > res["segs"].shape[1]):
             raise _lib.SwkError("more regions in a frame than seg_cap")      # cannot happen: labels are u8
-        regionprops_lists = [img.regionprops_from_records(res["segs"][i, :res["nseg"][i]]) for i in range(n)]
-        segment_images = [img.extract_segment_images(rps, frame, min_seg_size, crop_region)
-                          for frame, rps in zip(self.get_queue(), regionprops_lists)]
-        self.store_segmented_queue(regionprops_lists, segment_images)
+        # the classifier that scored the last window gets this one's segments right away: its forward runs while the
+        # Python objects below are made.  A window whose scores nobody asked for turns that off again.
+        prev, self._last_batch = self._last_batch, None
+        if prev is not None and not prev.used:
+            self._classifier_hint = None
+        batch = WindowBatch(ctx, generation, int(nseg.sum()), min_seg_size, queue=self) if stack.ndim == 4 else None
+        self._last_batch = batch
+        hint = self._classifier_hint() if self._classifier_hint is not None else None
+        if hint is not None and batch is not None:
+            batch.launch(hint)
+        planes = res.get("planes")
+        if planes is not None:
+            for key, name in STAGE_KEYS.items():
+                for i, slot in enumerate(self):
+                    slot.processed_frames[name] = (lambda k=key, i=i, p=planes: p.read(k, i))
+        k = 0
+        for i, slot in enumerate(self):
+            props = img.regionprops_from_records(res["segs"][i, :nseg[i]])
+            slot.segments = segs = [Segment(rp, slot.frame_number, slot.timestamp, img.segment_image_getter(rp, slot.frame, min_seg_size, crop_region))
+                                    for rp in props]
+            if batch is not None:
+                for s in segs:
+                    s._batch, s._index = batch, k
+                    k += 1
 
 
-def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, params=None):
+def _margin_rect(frame_shape, crop_region, min_seg_size):
+    """(ya, yb, xa, xb) of the ROI plus half the minimum segment size, clipped to the frame, and the ROI (x0, y0, x1, y1) clipped."""
+    Hf, Wf = frame_shape[:2]
+    (x0, y0), (x1, y1) = crop_region
+    x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, Wf), min(y1, Hf)
+    my, mx = int(min_seg_size[0]) // 2, int(min_seg_size[1]) // 2
+    return (max(y0 - my, 0), min(y1 + my, Hf), max(x0 - mx, 0), min(x1 + mx, Wf)), (x0, y0, x1, y1)
+
+
+def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, params=None, classifier=None):
     """Several FrameQueue-fuls in ONE library call.  windows: list of (frames, frame_numbers, timestamps) triples as
     FrameReader.get_n_frames returns them (oldest frame first), all of the same length n.  Returns one list of Frame
     objects per window in POP order (oldest first, the order __main__.py:81-92 consumes them), segments attached
     exactly as preprocess_queue + segment_queue would have (data_structures.py:171-217).  Windows are independent in
-    the reference too (the queue is emptied between them), so batching changes nothing but the launch count."""
+    the reference too (the queue is emptied between them), so batching changes nothing but the launch count.
+    classifier: its scoring of the batch's segments is started on the GPU before the Python objects are made."""
     if not windows:
         return []
     n = len(windows[0][0])
-    (x0, y0), (x1, y1) = crop_region
-    stack = np.empty((len(windows) * n, y1 - y0, x1 - x0) + windows[0][0][0].shape[2:], np.uint8)
+    first = windows[0][0][0]
+    (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(first.shape, crop_region, min_seg_size)
+    ctx = _lib.default_context(device)
+    stack = ctx.staging((len(windows) * n, yb - ya, xb - xa) + first.shape[2:])
     for w, (frames, _, _) in enumerate(windows):
         if len(frames) != n:
             raise ValueError("every window needs the same number of frames")
         for k, f in enumerate(frames):                       # queue index 0 = newest = last frame read (:134)
-            stack[w * n + (n - 1 - k)] = f[y0:y1, x0:x1]
-    ctx = _lib.default_context(device)
-    res = ctx.batch_run(stack, len(windows), n, params=params, stages=())
-    if np.any(res["nseg"] > res["segs"].shape[1]):
+            stack[w * n + (n - 1 - k)] = f[ya:yb, xa:xb]
+    res = ctx.batch_run(stack, len(windows), n, crop=(x0 - xa, y0 - ya, x1 - x0, y1 - y0), params=params, stages=())
+    nseg = res["nseg"]
+    if np.any(nseg > res["segs"].shape[1]):
         raise _lib.SwkError("more regions in a frame than seg_cap")
+    batch = WindowBatch(ctx, ctx.generation, int(nseg.sum()), min_seg_size) if stack.ndim == 4 else None
+    if batch is not None and classifier is not None:
+        batch.launch(classifier)
+    starts = np.concatenate([[0], np.cumsum(nseg)]).tolist()
     out = []
     for w, (frames, numbers, stamps) in enumerate(windows):
         popped = []
         for k in range(n):                                   # oldest first
             slot = w * n + (n - 1 - k)
             fr = Frame(frames[k], numbers[k], stamps[k])
-            props = img.regionprops_from_records(res["segs"][slot, :res["nseg"][slot]])
-            fr.set_segments(props, img.extract_segment_images(props, frames[k], min_seg_size, crop_region))
+            props = img.regionprops_from_records(res["segs"][slot, :nseg[slot]])
+            fr.segments = [Segment(rp, numbers[k], stamps[k], img.segment_image_getter(rp, frames[k], min_seg_size, crop_region))
+                           for rp in props]
+            if batch is not None:
+                for j, sg in enumerate(fr.segments, starts[slot]):
+                    sg._batch, sg._index = batch, j
             popped.append(fr)
         out.append(popped)
     return out

@@ -200,6 +200,33 @@ def get_segment_properties(frame):
     return regionprops_from_records(segs)
 
 
+def segment_crop_box(bbox, frame_shape, min_seg_size, crop_region):
+    """The rows / columns of the full frame extract_segment_images slices for one region (image_filtering.py:345-366)."""
+    r0, c0, r1, c1 = bbox
+    h, w = r1 - r0, c1 - c0
+    if h < min_seg_size[0]:
+        d = min_seg_size[0] - h
+        r0 -= d // 2
+        r1 += d - d // 2
+    if w < min_seg_size[1]:
+        d = min_seg_size[1] - w
+        c0 -= d // 2
+        c1 += d - d // 2
+    oy, ox = crop_region[0][1], crop_region[0][0]
+    return max(r0 + oy, 0), max(r1 + oy, 0), max(c0 + ox, 0), max(c1 + ox, 0)
+
+
+def segment_image_getter(segment, frame, min_seg_size, crop_region):
+    """Zero-argument callable that cuts one region's segment image (the same view extract_segment_images makes) when it is
+    first needed: data_structures.Segment resolves it on the first read of .segment_image."""
+    bbox = segment.bbox
+
+    def cut():
+        r0, r1, c0, c1 = segment_crop_box(bbox, frame.shape, min_seg_size, crop_region)
+        return frame[r0:r1, c0:c1]
+    return cut
+
+
 def extract_segment_images(segments, frame, min_seg_size, crop_region):
     """image_filtering.py:338-369: expand each bbox to at least min_seg_size (floor/ceil split),
     translate by the crop origin and slice the FULL frame (views).

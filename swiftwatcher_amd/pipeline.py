@@ -6,7 +6,7 @@ reference FrameReader's read_frame / get_n_frames / total_frames (swiftwatcher_a
 frames)."""
 from .data_structures import FrameQueue, segment_windows
 from .io_frames import ArrayReader
-from .segment_tracking import SegmentTracker
+from .segment_tracking import SegmentTracker, apply_hungarian_algorithm
 from . import event_classification as ec
 from . import image_filtering as img
 
@@ -40,7 +40,7 @@ def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size
                         triple = reader.get_n_frames(n=queue_size)                  # :73 (pads with null frames)
                         windows.append(triple)
                         ahead += sum(1 for k in triple[1] if k >= 0)                # null frames are not counted (:146-147)
-                    ready.put(segment_windows(windows, crop_region, min_seg_size, device=device))
+                    ready.put(segment_windows(windows, crop_region, min_seg_size, device=device, classifier=classifier))
                 ready.put(None)
             except BaseException as exc:                                            # surfaces in the consumer
                 ready.put(exc)
@@ -70,7 +70,12 @@ def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size
             frame = queue.pop_frame()
             if classifier is not None:                                         # :84-85 (--classify)
                 frame.segments = classifier(frame.segments)
-            tracker.step(frame)                                                # :87-92
+            tracker.set_current_frame(frame)                                   # :87-92, call by call
+            cost_matrix = tracker.formulate_cost_matrix()
+            tracker.store_assignments(apply_hungarian_algorithm(cost_matrix))
+            tracker.link_matching_segments()
+            tracker.check_for_events()
+            tracker.cache_current_frame()
     return tracker.detected_events
 
 

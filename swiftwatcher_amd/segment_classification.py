@@ -393,7 +393,12 @@ class CroppedSqueezeNet10:
             else:
                 place(conv2d(sq, layer.expand3x3.weight, None), layer.expand3x3.bias, dest, 0, cn, doff, c1)
             x = dest
-        s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
+        # the 512 -> 2 head (1 x 1 convolution + ReLU + spatial sum) as a plain matrix product over the channels-last pixels: no
+        # convolution library on this path, hence no kernel search per batch shape
+        head = m.classifier[1]
+        px = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])                       # (B * 11 * 11, 512): a view of the NHWC memory
+        s = torch.relu(torch.nn.functional.linear(px, head.weight.view(head.out_channels, -1), head.bias))
+        s = s.view(k, -1, head.out_channels).sum(dim=1)
         return (s + self.ring_sum) / self.n_pos
 
     def _aux_buffers(self, batch):
@@ -454,11 +459,9 @@ class SegmentClassifier:
                                    "explicitly to run the torch CPU kernels instead")
             device = "cuda:0"
         self.device = torch.device(device)
-        if self.device.type == "cuda" and os.environ.get("SWK_CUDNN_BENCHMARK", "1") == "1":
-            # MIOpen's exhaustive find instead of its immediate-mode heuristic: the search runs once per tensor shape
-            # (this classifier pads its batches to three sizes) and picks convolution kernels that are 10 % faster on
-            # these shapes (0.48 instead of 0.44 of the f32 matrix peak, measured); a process-wide torch setting
-            torch.backends.cudnn.benchmark = True
+        # MIOpen's exhaustive find instead of its immediate-mode heuristic for the convolutions left to it (the head; everything with
+        # the fused kernels off): scoped to this classifier's forwards (torch.backends.cudnn.flags in _run), not set process-wide
+        self._cudnn_benchmark = self.device.type == "cuda" and os.environ.get("SWK_CUDNN_BENCHMARK", "1") == "1"
         self.batch_size = batch_size
         self.model = setup_model(2)
         state = torch.load(model_path, map_location="cpu", weights_only=True)
@@ -474,6 +477,9 @@ class SegmentClassifier:
         # current stream; net_time() sums them
         self.timing = False
         self._events = []
+        # device-side input buffers of scores_from_device / predict_last_batch: two slots, each with the event of the last forward
+        # that read it (a slot is handed to the library's stream again only after that event)
+        self._slots = None
 
     def preprocess(self, segment_images, window=False):
         """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device, or with
@@ -488,6 +494,8 @@ class SegmentClassifier:
             torch.cuda.current_stream(self.device).synchronize()     # the library fills x on its own stream
             _lib.default_context(self.device.index or 0).classifier_input(segment_images, IMAGENET_MEAN, IMAGENET_STD,
                                                                           net_ptr=x.data_ptr(), pad=PAD - lo)
+            # (x is a fresh allocation: the caching allocator may hand out a block whose last reader is still queued on
+            # torch's stream -- hence the synchronize above, before the library's stream writes it)
             return x
         patches = np.stack([resize_segment(im) for im in segment_images])              # (B, 24, 24, 3) u8
         t = torch.from_numpy(patches).to(self.device).permute(0, 3, 1, 2).to(torch.float32).div_(255.0)   # ToTensor
@@ -498,28 +506,34 @@ class SegmentClassifier:
 
     @torch.no_grad()
     def _bucket(self, k):
-        """Batch size the network is run at for k inputs: MIOpen searches for kernels once per tensor shape (seconds; conv1 and
-        the head are its), and a counting loop hands over a different number of segments every call -- so on the GPU the
-        batch is padded to 64, or to a multiple of 512 up to batch_size (at most batch_size / 512 + 1 shapes).  The padding
-        rows are scored and thrown away."""
+        """Batch size the network is run at for k inputs: a counting loop hands over a different number of segments every call, and
+        a few fixed shapes keep the per-shape state small (persistent tiles are sized by the largest; with the fused kernels off
+        MIOpen searches once per shape) -- so on the GPU the batch is padded to a multiple of 64 up to 512 rows, beyond that to a
+        multiple of 512 up to batch_size.  The padding rows are scored and thrown away."""
         if self.device.type != "cuda":
             return k
-        if k <= 64 < self.batch_size:
-            return 64
         if k >= self.batch_size:
             return max(self.batch_size, k)
+        if k <= 512:                         # a FrameQueue window's worth of segments: 64-row steps
+            return min(self.batch_size, -(-k // 64) * 64)
         return min(self.batch_size, -(-k // 512) * 512)
+
+    def _forward(self, x):
+        if self._cudnn_benchmark:
+            with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+                return self.cropped(x) if self.cropped is not None else self.model(x)
+        return self.cropped(x) if self.cropped is not None else self.model(x)
 
     def _run(self, x, k):
         """Scores of the first k rows of x (x has _bucket(k) rows)."""
         if self.timing and self.device.type == "cuda":
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            out = (self.cropped(x) if self.cropped is not None else self.model(x))[:k]
+            out = self._forward(x)[:k]
             b.record()
             self._events.append((a, b, int(x.shape[0])))
             return out
-        return (self.cropped(x) if self.cropped is not None else self.model(x))[:k]
+        return self._forward(x)[:k]
 
     def net_time(self, reset=True):
         """(milliseconds, rows pushed through the network, forwards) of the timed forwards since the last reset."""
@@ -542,37 +556,35 @@ class SegmentClassifier:
             out.append(self._run(x, k))
         return torch.cat(out) if out else torch.zeros((0, 2), device=self.device)
 
+    def _device_slots(self, side, nhwc):
+        key = (side, nhwc, self.batch_size)
+        if self._slots is None or self._slots[0] != key:
+            fmt = torch.channels_last if nhwc else torch.contiguous_format
+            xb = [torch.empty((self.batch_size, 3, side, side), dtype=torch.float32, device=self.device, memory_format=fmt) for _ in range(2)]
+            fb = [torch.empty((self.batch_size,), dtype=torch.int32, device=self.device) for _ in range(2)]
+            torch.cuda.current_stream(self.device).synchronize()          # fresh blocks: nothing queued on torch's stream may still read them
+            self._slots = (key, xb, fb, [None, None])
+        return self._slots[1:]
+
     @torch.no_grad()
-    def scores_from_device(self, ctx, inp, frame_hw, segs, nseg, seg_cap, min_seg_size=(24, 24)):
-        """The classifier on a whole batch_run without leaving the GPU: inp is the swk_input of that call (device
-        frames), segs / nseg its device region records (torch tensors).  The crops of extract_segment_images
-        (image_filtering.py:338-369) are cut, resized and normalised by swk_segment_inputs into the network's input
-        tensor, batch_size segments at a time.  Returns (scores (T, 2), frame index (T,) int32), both on the device,
-        segments in frame order then ascending label -- the order FrameQueue hands them to __call__."""
+    def _scores_device(self, cut):
+        """Scores of a device-resident batch.  cut(net_ptr, frame_ptr, net_cap, first, pad, channels_last) -> (total, skipped) writes
+        the network inputs of segments [first, first + net_cap) (a library call: its own stream, synchronous).  Two input slots: the
+        library cuts and resamples chunk i + 1 while PyTorch's stream runs the network on chunk i; a slot is written again only after
+        the forward that read it has finished (its event) -- also across calls, the slots and events belong to the classifier."""
         if self.device.type != "cuda":
-            raise RuntimeError("scores_from_device needs the GPU")
+            raise RuntimeError("device-resident scoring needs the GPU")
         pad = PAD - CroppedSqueezeNet10.IN_LO if self.cropped is not None else PAD
         side = RESIZE + 2 * pad
         bs = self.batch_size
         # the cropped network's convolution kernels read channels-last: the input is written that way (a copy per forward less)
         nhwc = self.cropped is not None and self.cropped.memory_format == torch.channels_last
-        # two input buffers: the library cuts and resamples chunk i + 1 (on its own stream, and waits for it) while PyTorch's
-        # stream runs the network on chunk i; a buffer is written again only after the forward that read it has finished
-        xb = [torch.empty((bs, 3, side, side), dtype=torch.float32, device=self.device,
-                          memory_format=torch.channels_last if nhwc else torch.contiguous_format) for _ in range(2)]
-        fb = [torch.empty((bs,), dtype=torch.int32, device=self.device) for _ in range(2)]
-        done = [None, None]
+        xb, fb, done = self._device_slots(side, nhwc)
 
         def produce(slot, first):
             if done[slot] is not None:
                 done[slot].synchronize()
-            ctx.set_classifier_input_layout(nhwc)
-            try:
-                total, skipped = ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN,
-                                                    IMAGENET_STD, xb[slot].data_ptr(), bs, first=first, pad=pad,
-                                                    min_seg_size=min_seg_size, seg_frame_ptr=fb[slot].data_ptr())
-            finally:
-                ctx.set_classifier_input_layout(False)
+            total, skipped = cut(xb[slot].data_ptr(), fb[slot].data_ptr(), bs, first, pad, nhwc)
             if skipped:
                 raise RuntimeError("%d segment boxes were empty or larger than 512 pixels" % skipped)
             return total
@@ -595,13 +607,38 @@ class SegmentClassifier:
             return torch.zeros((0, 2), device=self.device), torch.zeros((0,), dtype=torch.int32, device=self.device)
         return torch.cat(scores), torch.cat(frames_of)
 
+    def scores_from_device(self, ctx, inp, frame_hw, segs, nseg, seg_cap, min_seg_size=(24, 24)):
+        """The classifier on a whole batch_run without leaving the GPU: inp is the swk_input of that call (device
+        frames), segs / nseg its device region records (torch tensors).  The crops of extract_segment_images
+        (image_filtering.py:338-369) are cut, resized and normalised by swk_segment_inputs into the network's input
+        tensor, batch_size segments at a time.  Returns (scores (T, 2), frame index (T,) int32), both on the device,
+        segments in frame order then ascending label -- the order FrameQueue hands them to __call__."""
+        def cut(net_ptr, frame_ptr, cap, first, pad, nhwc):
+            return ctx.segment_inputs(inp, frame_hw, segs.data_ptr(), nseg.data_ptr(), seg_cap, IMAGENET_MEAN, IMAGENET_STD, net_ptr, cap,
+                                      first=first, pad=pad, min_seg_size=min_seg_size, seg_frame_ptr=frame_ptr, channels_last=nhwc)
+        return self._scores_device(cut)
+
+    def predict_last_batch(self, ctx, generation, total, min_seg_size=(24, 24)):
+        """Predicted class of every segment of the batch `ctx` ran last (FrameQueue.segment_queue's window), in batch order: an int64
+        device tensor (total,), not waited for.  The inputs are cut from what that batch left on the device (swk_segment_inputs_last);
+        raises _lib.StaleBatch when the context has moved on."""
+        def cut(net_ptr, frame_ptr, cap, first, pad, nhwc):
+            return ctx.segment_inputs_last(generation, IMAGENET_MEAN, IMAGENET_STD, net_ptr, cap, first=first, pad=pad,
+                                           min_seg_size=min_seg_size, seg_frame_ptr=frame_ptr, channels_last=nhwc)
+        scores, _ = self._scores_device(cut)
+        if scores.shape[0] != total:
+            raise RuntimeError("the device holds %d segments, the window has %d" % (scores.shape[0], total))
+        return torch.max(scores, 1)[1]                                   # :36-39
+
     def classify_frames(self, frames):
         """__call__ for many frames with ONE scoring batch: every frame's segments replaced by the kept ones,
         relabelled 1..k per frame (:41-42)."""
         segs = [s for fr in frames for s in fr.segments]
         if not segs:
             return
-        pred = torch.max(self.scores([s.segment_image for s in segs]), 1)[1].cpu().numpy()
+        pred = self._window_predictions(segs)                 # segments of one segment_windows / segment_queue call: device-resident
+        if pred is None:
+            pred = torch.max(self.scores([s.segment_image for s in segs]), 1)[1].cpu().numpy()
         i = 0
         for fr in frames:
             kept = []
@@ -613,13 +650,31 @@ class SegmentClassifier:
                 s.label = j + 1
             fr.segments = kept
 
+    def _window_predictions(self, segments):
+        """Segments that FrameQueue.segment_queue made carry their window (data_structures.WindowBatch) and their index in it:
+        the first call of a window scores ALL its segments in one device-resident batch, the others look their rows up.  None
+        when the segments are not such a group or the window's device state is gone (the caller then scores their images)."""
+        if self.device.type != "cuda":
+            return None
+        batch = getattr(segments[0], "_batch", None)
+        if batch is None or any(getattr(s, "_batch", None) is not batch for s in segments):
+            return None
+        if (self.device.index or 0) != batch.ctx.device:
+            return None
+        table = batch.predictions(self)
+        if table is None:
+            return None
+        return [table[s._index] for s in segments]
+
     def __call__(self, segments):
         """:26-44: keep segments whose argmax is class 1 (ties / all-zero scores give 0 and are
         dropped, as torch.max does), relabel the kept ones 1..k."""
         if not segments:
             return []
-        score = self.scores([s.segment_image for s in segments])
-        pred = torch.max(score, 1)[1].cpu().numpy()
+        pred = self._window_predictions(segments)
+        if pred is None:
+            score = self.scores([s.segment_image for s in segments])
+            pred = torch.max(score, 1)[1].cpu().numpy()
         kept = [s for s, y in zip(segments, pred) if y == 1]
         for i, s in enumerate(kept):
             s.label = i + 1

@@ -57,27 +57,26 @@ class SegmentTracker:
     def formulate_cost_matrix(self):
         """:46-102, one C call instead of a Python double loop with scipy/math scalar calls."""
         prev, curr = self.cached_frame.segments, self.current_frame.segments
-        n_prev = len(prev)
-        prev_c = [s.centroid for s in prev]
-        hist0 = [s.segment_history[0].centroid if s.segment_history else (0.0, 0.0) for s in prev]
-        has_hist = [1 if s.segment_history else 0 for s in prev]
-        curr_c = [s.centroid for s in curr]
-        return _lib.track_costs(np.array(prev_c, np.float64).reshape(n_prev, 2), np.array(hist0, np.float64).reshape(n_prev, 2),
-                                np.array(has_hist, np.uint8), np.array(curr_c, np.float64).reshape(len(curr), 2))
+        flat = [c for s in prev for c in s.centroid]
+        flat += [c for s in prev for c in (s.segment_history[0].centroid if s.segment_history else (0.0, 0.0))]
+        flat += [c for s in curr for c in s.centroid]
+        flags = bytes([1 if s.segment_history else 0 for s in prev])
+        return _lib.track_costs_packed(np.array(flat, np.float64), flags, len(prev), len(curr))
 
     def store_assignments(self, assignments):
         """:104-131."""
         prev, curr = self.cached_frame.segments, self.current_frame.segments
         n_prev = len(prev)
+        targets = assignments.tolist() if hasattr(assignments, "tolist") else list(assignments)
         for prev_label in range(n_prev):
-            target = int(assignments[prev_label]) - n_prev
+            target = targets[prev_label] - n_prev
             if target >= 0:
                 prev[prev_label].status = target
                 curr[target].status = prev_label
             else:
                 prev[prev_label].status = "D"
         for curr_label in range(len(curr)):
-            if int(assignments[n_prev + curr_label]) - n_prev == curr_label:
+            if targets[n_prev + curr_label] - n_prev == curr_label:
                 curr[curr_label].status = "A"
 
     def link_matching_segments(self):

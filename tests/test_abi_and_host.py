@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(lib, name), "libswk.so does not export %s" % name
     from swiftwatcher_amd import _lib
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().swk_abi_version() == 1
+    assert _lib.load().swk_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layouts_and_defaults(built_lib):

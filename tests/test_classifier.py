@@ -440,9 +440,8 @@ def test_fused_conv3x3_kernel_against_torch():
 def test_winograd_filter_transform_host():
     """swk_winograd_f2x2_3x3_weights (host code): U = G g G^T of every filter, in the kernel's operand layout
     input channel 16 chunk + 8 (k half) + 4 quad + j, output channels padded to whole column blocks; one layout per kernel
-    configuration: [position][h][chunk][k half][quad][cg * 32 + r][4] with output channel 32 NBW cg + 32 h + r (NBW = 1 column
-    block per wave by default, 2 behind the measurement knob); 64 -> 256 with one block per wave keeps every wave's 2 KB of a phase
-    contiguous: [position][chunk][cg][k half][quad][r][4], output channel 32 cg + r."""
+    configuration: [position][chunk][k half][quad][cg * 32 + r][4] with output channel 32 cg + r (one column block per
+    wave); 64 -> 256 keeps every wave's 2 KB of a phase contiguous: [position][chunk][cg][k half][quad][r][4]."""
     import ctypes
     from swiftwatcher_amd import _lib
     lib = _lib.load()
@@ -459,22 +458,18 @@ def _check_winograd_layouts(lib, rng, cout, cin):
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum("ak,oikl,bl->abio", G, w.astype(np.float64), G)              # [xi][nu][ci][co]
-    try:
-        for nbw in (2, 1):
-            assert lib.swk_set_cnn_tuning(1, 1 if nbw == 1 else 0) == 0
-            CG = -(-cout // (32 * nbw))
-            out = np.full(16 * cin * nbw * 32 * CG, np.nan, np.float32)
-            assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
-            if not (nbw == 1 and (cin, cout) == (64, 256)):         # shared phase blocks: p, h, chunk, k half, quad, cg, r, j
-                out = out.reshape(16, nbw, cin // 16, 2, 2, CG, 32, 4)
-                got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 32 * nbw * CG)      # -> [xi][nu][channel][64 cg + 32 h + r]
-            else:                # 64 -> 256, private slices: a wave's 2 KB of a phase contiguous: p, chunk, cg, k half, quad, r, j
-                out = out.reshape(16, cin // 16, CG, 2, 2, 32, 4)
-                got = out.transpose(0, 1, 3, 4, 6, 2, 5).reshape(4, 4, cin, 32 * CG)               # -> [xi][nu][channel][32 cg + r]
-            assert np.array_equal(got[..., :cout], U.astype(np.float32))
-            assert not got[..., cout:].any()
-    finally:
-        assert lib.swk_set_cnn_tuning(1, 1) == 0
+    nbw = 1
+    CG = -(-cout // (32 * nbw))
+    out = np.full(16 * cin * nbw * 32 * CG, np.nan, np.float32)
+    assert lib.swk_winograd_f2x2_3x3_weights(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    if (cin, cout) != (64, 256):         # shared phase blocks: p, h, chunk, k half, quad, cg, r, j
+        out = out.reshape(16, nbw, cin // 16, 2, 2, CG, 32, 4)
+        got = out.transpose(0, 2, 3, 4, 7, 5, 1, 6).reshape(4, 4, cin, 32 * nbw * CG)      # -> [xi][nu][channel][32 cg + r]
+    else:                # 64 -> 256, private slices: a wave's 2 KB of a phase contiguous: p, chunk, cg, k half, quad, r, j
+        out = out.reshape(16, cin // 16, CG, 2, 2, 32, 4)
+        got = out.transpose(0, 1, 3, 4, 6, 2, 5).reshape(4, 4, cin, 32 * CG)               # -> [xi][nu][channel][32 cg + r]
+    assert np.array_equal(got[..., :cout], U.astype(np.float32))
+    assert not got[..., cout:].any()
 
 
 @pytest.mark.gpu
@@ -494,8 +489,7 @@ def test_winograd_conv3x3_kernel_against_torch():
         (1, 64, 256, 3, 1, 0, 256, 0), (1, 32, 128, 5, 3, 0, 128, 0), (70, 64, 256, 7, 5, 0, 256, 0), (33, 48, 192, 4, 2, 0, 192, 0),
         (7, 16, 64, 12, 10, 0, 128, 64), (5, 16, 64, 14, 12, 0, 128, 64), (130, 16, 64, 5, 3, 0, 64, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    for knob, (n, cin, cout, t, dH, off, dC, c_off) in [(1, c) for c in cases] + [(0, c) for c in cases[:6]]:          # 16 -> 64 only with one block per wave
-        assert lib.swk_set_cnn_tuning(1, knob) == 0          # one (default) or two column blocks per wave: different kernels and layouts
+    for n, cin, cout, t, dH, off, dC, c_off in cases:
         x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         wcpu = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).contiguous()
         wgt = wcpu.to(dev)
@@ -524,7 +518,124 @@ def test_winograd_conv3x3_kernel_against_torch():
         mask = torch.ones_like(dst, dtype=torch.bool)
         mask[:, c_off:c_off + cout, off:off + o, off:off + o] = False
         assert bool((dst[mask] == -7.0).all())
-    assert lib.swk_set_cnn_tuning(1, 1) == 0
     # shapes outside the Fire ratio are refused (the caller takes the direct kernel)
     assert lib.swk_nhwc_conv3x3_winograd_bias_relu_place(stream, x.data_ptr(), 1, 4, 16, ww.data_ptr(), bias.data_ptr(), 32,
                                                          dst.data_ptr(), 2, 2, 32, 0, 0, 0) != 0
+
+
+def _calibrated_classifier(crops, seed, tmp_path, margin=2e-4):
+    """A random-weight classifier whose head keeps some but not all of `crops`, no decision closer to the boundary than
+    `margin` (so float32 summation order cannot flip one); returns (SegmentClassifier on the GPU, state dict, oracle keep flags)."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    sd = ref.calibrate_head(ref.random_state_dict(seed), crops[::3])
+    scores, _ = ref.classify(sd, crops)
+    d = np.sort((scores[:, 1] - scores[:, 0]).astype(np.float64))
+    mid = d[len(d) // 3: 2 * len(d) // 3]
+    gap = int(np.argmax(np.diff(mid)))
+    sd["classifier.1.bias"] = sd["classifier.1.bias"] - torch.tensor([0.0, float(0.5 * (mid[gap] + mid[gap + 1]))])
+    scores, keep = ref.classify(sd, crops)
+    assert np.abs(scores[:, 1] - scores[:, 0]).min() > margin
+    assert 0.2 * len(crops) < keep.sum() < 0.8 * len(crops)
+    path = tmp_path / ("w%d.pt" % seed)
+    torch.save(sd, path)
+    return SegmentClassifier(str(path)), sd, keep
+
+
+@pytest.mark.gpu
+def test_window_score_table_equals_per_frame_calls(tmp_path):
+    """__main__.py:84-85 calls classifier(frame.segments) once per popped frame.  Here the first call of a window scores ALL
+    its segments in one device-resident batch (swk_segment_inputs_last on what segment_queue left on the GPU: the ROI frames
+    with a margin of half the minimum segment size, and the region records) and the other calls look their rows up.  Kept
+    segments and labels must equal (a) the oracle classifier on the reference's crops (extract_segment_images' views of the FULL
+    frame: boxes near the ROI's edge grow into the margin), (b) this classifier's per-call image path, which still serves when the
+    context has moved on in between.  From the second window on the scoring starts inside segment_queue; a window whose scores
+    nobody asked for switches that off again."""
+    from swiftwatcher_amd import synthetic, _lib
+    from swiftwatcher_amd.data_structures import FrameQueue
+    from oracle import reference_path as orc
+    crop_region = [(60, 50), (60 + 212, 50 + 106)]
+    n, windows = 21, 3
+    clip = synthetic.full_frames(31, n * windows, crop_region, frame_hw=(220, 340), birds=10, bird_len=(14, 24), bird_wid=(6, 10))[::-1].copy()
+    clip[:, :50] = (clip[:, 50:100][:, ::-1] // 2 + 40)        # structure OUTSIDE the ROI: a crop that reaches into the margin sees it
+    clip[:, :, :60] = (clip[:, :, 60:120][:, :, ::-1] // 2 + 30)
+
+    def run(mode, clf):
+        q = FrameQueue()
+        out = []
+        launches = 0
+        for w in range(windows):
+            fr = [clip[w * n + i] for i in range(n)]
+            q.push_list_of_frames(fr, list(range(w * n, w * n + n)), ["t"] * n)
+            q.preprocess_queue(crop_region, None)
+            q.segment_queue((24, 24), crop_region)
+            if mode == "window" and w >= 1:
+                assert q._last_batch._tables, "the hinted classifier's forward was not started inside segment_queue"
+            if mode == "stale":                                 # another batch on the same context before the first classifier call
+                _lib.default_context(0).batch_run(np.ascontiguousarray(clip[:4, 50:80, 60:100]), 1, 4, stages=())
+            while not q.is_empty():
+                f = q.pop_frame()
+                before = [(s.bbox, s.segment_image) for s in f.segments]
+                if mode == "images":
+                    for s in f.segments:
+                        del s._batch
+                kept = clf(f.segments)
+                assert [s.label for s in kept] == list(range(1, len(kept) + 1))
+                out.append((f.frame_number, before, [s.bbox for s in kept]))
+            if mode == "stale":
+                assert not q._last_batch._tables
+        return out
+
+    # oracle: crops of the full frame by the reference's box rule, oracle classifier
+    q = FrameQueue()
+    crops, boxes = [], []
+    for w in range(windows):
+        fr = [clip[w * n + i] for i in range(n)]
+        q.push_list_of_frames(fr, list(range(w * n, w * n + n)), ["t"] * n)
+        q.preprocess_queue(crop_region, None)
+        q.segment_queue((24, 24), crop_region)
+        while not q.is_empty():
+            f = q.pop_frame()
+            for s in f.segments:
+                r0, c0, r1, c1 = orc.segment_crop_box(s.bbox, (24, 24), crop_region)
+                crops.append(f.frame[max(r0, 0):max(r1, 0), max(c0, 0):max(c1, 0)])
+                boxes.append((f.frame_number, s.bbox))
+    assert len(crops) > 200
+    reach = sum(1 for (_, b) in boxes if b[0] < 12 or b[1] < 12)
+    assert reach >= 5, "no segment near the ROI's top / left edge: the margin is not exercised"
+    clf, sd, keep = _calibrated_classifier(crops, 5, tmp_path)
+    expect = {}
+    for (fn, b), kp in zip(boxes, keep):
+        expect.setdefault(fn, [])
+        if kp:
+            expect[fn].append(b)
+    got = run("window", clf)
+    for fn, before, kept in got:
+        assert kept == expect.get(fn, []), fn
+    for mode in ("images", "stale"):
+        other = run(mode, clf)
+        assert [(a, c) for a, _, c in other] == [(a, c) for a, _, c in got], mode
+    # a window that nobody classifies turns the eager start off again
+    q = FrameQueue()
+    for w in range(3):
+        fr = [clip[w * n + i] for i in range(n)]
+        q.push_list_of_frames(fr, list(range(n)), ["t"] * n)
+        q.preprocess_queue(crop_region, None)
+        q.segment_queue((24, 24), crop_region)
+        if w == 0:
+            clf(q[20].segments)
+            assert q._classifier_hint is not None
+        if w == 1:
+            assert q._last_batch._tables                        # started eagerly, then never used
+        if w == 2:
+            assert q._classifier_hint is None and not q._last_batch._tables
+        while not q.is_empty():
+            q.pop_frame()
+    # events of a deep copy (what __main__.py:100 returns) carry plain data only
+    import copy
+    q.push_list_of_frames([clip[i] for i in range(n)], list(range(n)), ["t"] * n)
+    q.preprocess_queue(crop_region, None)
+    q.segment_queue((24, 24), crop_region)
+    some = [s for f in q for s in f.segments][:3]
+    cp = copy.deepcopy(some)
+    assert all(not hasattr(c, "_batch") for c in cp) and all(np.array_equal(c.segment_image, s.segment_image) for c, s in zip(cp, some))

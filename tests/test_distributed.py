@@ -100,3 +100,24 @@ def test_one_rank_group_runs_the_collectives_rccl():
     with a one-rank group on the GPU: the collective code path of distributed.py executes on hardware (a child
     process, so the test session itself never joins a process group)."""
     _one_rank_group("nccl")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun: the parent (which never touches a GPU) starts two fresh rank processes and
+    relays rank 0's line.  --rehearse-launch runs the whole multi-rank protocol (process group, barrier, max-over-ranks clock,
+    gather of the per-rank counts) around empty steps, so this runs on a CPU-only host with gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWK_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch", "--steps", "2", "--windows", "4"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["launched_by"] == "bench.py" and line["backend"] == "gloo"
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["frames"] == 4 * 64 * 2 for r in line["per_rank"])

@@ -611,3 +611,79 @@ def test_swift_count_on_a_clip_matches_cpu_pipeline(orc):
         assert count_b == count
         assert [[(s.parent_frame_number, s.label, s.bbox, s.centroid) for s in e] for e in events_b] == \
                [[(s.parent_frame_number, s.label, s.bbox, s.centroid) for s in e] for e in events]
+
+
+def test_framequeue_stage_images_stay_on_the_gpu_until_read(orc):
+    """The default FrameQueue() (keep_stages=True, as the reference constructs it, data_structures.py:120) stores the six
+    stage images as device-resident values: nothing is copied until a key is read, a read copies ONE image, the values
+    survive the queue's next window (each window has its own device buffer, handed back to the context's free list when
+    the last Frame that refers to it is gone)."""
+    from swiftwatcher_amd import synthetic, _lib
+    from swiftwatcher_amd.data_structures import FrameQueue, _LazyStages
+    from collections import OrderedDict
+    crop_region = [(40, 30), (40 + 124, 30 + 62)]          # a ROI size no other test uses: its free list starts empty
+    n = 21
+    q = FrameQueue()
+    kept = []
+    refs = []
+    for seed in (9, 10):
+        frames = synthetic.full_frames(seed, n, crop_region, frame_hw=(128, 200), birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+        q.push_list_of_frames([frames[i] for i in range(n - 1, -1, -1)], list(range(n)), ["t"] * n)
+        q.preprocess_queue(crop_region, (300, 150))
+        q.segment_queue((24, 24), crop_region)
+        for f in q:                                          # nothing resolved yet
+            raw = [OrderedDict.__getitem__(f.processed_frames, k) for k in ("RPCA", "bilateral", "thresh_15", "opened", "cc_labeling")]
+            assert all(callable(v) for v in raw)
+        refs.append(orc.window(np.ascontiguousarray(frames[:, 30:92, 40:164])))
+        kept.append([q.pop_frame() for _ in range(n)][::-1])          # queue order again: index 0 = newest
+    ctx = _lib.default_context(0)
+    pool_key = (21 * 62 * 124 + 3) // 4 * 4 * 6
+    assert len(ctx._plane_pool.get(pool_key, [])) == 0                     # both windows' buffers are still in use
+    names = {"grayscale": "gray", "RPCA": "rpca", "bilateral": "bilateral", "thresh_15": "thresh", "opened": "opened",
+             "cc_labeling": "labels"}
+    for frames_of_window, ref in zip(kept, refs):                     # the FIRST window is read after the second ran
+        for pos in (0, 7, 20):
+            f = frames_of_window[pos]
+            assert isinstance(f.processed_frames, _LazyStages)
+            for name, key in names.items():
+                np.testing.assert_array_equal(f.get_processed_frame(name), ref[key][pos], err_msg=name)
+            assert not callable(OrderedDict.__getitem__(f.processed_frames, "opened"))        # resolved values are kept
+    del kept, frames_of_window, f
+    import gc
+    gc.collect()
+    assert len(ctx._plane_pool[pool_key]) == 2                             # handed back, ready for the next windows
+    q2 = FrameQueue(keep_stages=False)
+    frames = synthetic.full_frames(11, n, crop_region, frame_hw=(128, 200), birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+    q2.push_list_of_frames([frames[i] for i in range(n - 1, -1, -1)], list(range(n)), ["t"] * n)
+    q2.preprocess_queue(crop_region, None)
+    q2.segment_queue((24, 24), crop_region)
+    assert list(q2[0].processed_frames.keys()) == ["crop", "grayscale"]
+
+
+def test_roi_at_the_frame_corner_and_gray_frames(orc):
+    """The margin FrameQueue stages around the ROI is clipped to the frame (ROI in the top-left corner: no margin on two
+    sides); single-channel frames (image_filtering.py:193-194) go through without a classifier batch."""
+    from swiftwatcher_amd import synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    n = 21
+    for crop_region, hw in (([(0, 0), (120, 60)], (70, 130)), ([(10, 4), (130, 64)], (64, 130))):
+        frames = synthetic.full_frames(5, n, crop_region, frame_hw=hw, birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+        (x0, y0), (x1, y1) = crop_region
+        ref = orc.window(np.ascontiguousarray(frames[:, y0:y1, x0:x1]))
+        q = FrameQueue()
+        q.push_list_of_frames([frames[i] for i in range(n - 1, -1, -1)], list(range(n)), ["t"] * n)
+        q.preprocess_queue(crop_region, None)
+        q.segment_queue((24, 24), crop_region)
+        for pos in range(n):
+            np.testing.assert_array_equal(q[pos].processed_frames["cc_labeling"], ref["labels"][pos])
+            assert [(s.label, s.bbox, s.centroid) for s in q[pos].segments] == [(s["label"], s["bbox"], s["centroid"]) for s in ref["segments"][pos]]
+    gray = np.ascontiguousarray(ref["gray"])
+    full = np.full((n, 64, 130), 128, np.uint8)
+    full[:, 4:64, 10:130] = gray
+    q = FrameQueue()
+    q.push_list_of_frames([full[i] for i in range(n - 1, -1, -1)], list(range(n)), ["t"] * n)
+    q.preprocess_queue(crop_region, None)
+    q.segment_queue((24, 24), crop_region)
+    for pos in range(n):
+        np.testing.assert_array_equal(q[pos].processed_frames["cc_labeling"], ref["labels"][pos])
+        assert all(not hasattr(s, "_batch") for s in q[pos].segments)

@@ -71,8 +71,6 @@ def main():
     ring = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     if _lib.load().swk_set_cnn_tuning(0, ring):
         raise SystemExit("swk_set_cnn_tuning refused %d" % ring)
-    if len(sys.argv) > 4 and _lib.load().swk_set_cnn_tuning(1, int(sys.argv[4])):
-        raise SystemExit("swk_set_cnn_tuning(1) refused")
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "w.pt")
         torch.save(ref.random_state_dict(0), path)
