@@ -142,6 +142,13 @@ int64_t swk_ctx_device_bytes(const swk_ctx *ctx);
  * chose a device would otherwise create a context on GPU 0), usable from any; no swk_ctx needed; free with swk_pinned_free. */
 int32_t swk_pinned_alloc(int32_t device, int64_t bytes, void **out);
 int32_t swk_pinned_free(void *p);
+/* Host-side staging (no GPU, no context): rows [y0, y0 + rows) x bytes [x_bytes, x_bytes + row_bytes) of each of `count` frames
+ * (frames[f] = address of frame f's first byte, row_stride bytes per row) copied densely into dst [count][rows][row_bytes] --
+ * the stack FrameQueue.segment_queue hands to swk_batch_run, i.e. crop_frame (image_filtering.py:199-203) for a whole window.
+ * threads > 1: the frames are split over a small persistent pool (video frames are cold in the caches; one core copies a
+ * 21-frame 1080p window's ROI in about half a millisecond). */
+int32_t swk_stage_frames(const uint8_t *const *frames, int32_t count, int64_t row_stride, int32_t y0, int32_t rows, int64_t x_bytes,
+                         int64_t row_bytes, uint8_t *dst, int32_t threads);
 /* Device memory on the context's GPU for outputs the caller wants to keep there (swk_output with planes_on_device, or
  * mem = SWK_MEM_DEVICE), and a synchronous copy of a piece of it to host memory.  The library never frees such a buffer
  * by itself; swk_device_free waits for the context's stream first. */

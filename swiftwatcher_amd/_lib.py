@@ -118,6 +118,7 @@ _SIGS = {
     "swk_roi_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "swk_pinned_alloc": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     "swk_pinned_free": (ctypes.c_int32, [ctypes.c_void_p]),
+    "swk_stage_frames": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
     "swk_prof_get": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
@@ -539,6 +540,24 @@ class Context:
         self._check(self._lib.swk_regionprops_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], seg_cap,
                                                  _ptr(segs), _ptr(nseg)))
         return (segs[0, :nseg[0]], int(nseg[0])) if single else (segs, nseg)
+
+
+def stage_frames(frames, y0, y1, x0, x1, dst, threads=4):
+    """dst[i] = frames[i][y0:y1, x0:x1] for a list of equally shaped uint8 frames (H, W[, C]) whose rows are contiguous, by
+    swk_stage_frames (threads of the library, GIL released); frames that do not qualify are copied by numpy."""
+    f0 = frames[0]
+    px = f0.strides[1] if f0.ndim >= 2 else 1
+    ok = all(f.dtype == np.uint8 and f.shape == f0.shape and f.strides == f0.strides for f in frames) and \
+        f0.ndim in (2, 3) and (f0.ndim == 2 or (f0.strides[2] == 1 and f0.strides[1] == f0.shape[2])) and \
+        (f0.ndim == 3 or f0.strides[1] == 1) and f0.strides[0] >= f0.shape[1] * px and dst.flags.c_contiguous
+    if not ok:
+        for i, f in enumerate(frames):
+            dst[i] = f[y0:y1, x0:x1]
+        return
+    ptrs = (ctypes.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+    rc = load().swk_stage_frames(ptrs, len(frames), f0.strides[0], y0, y1 - y0, x0 * px, (x1 - x0) * px, dst.ctypes.data, threads)
+    if rc:
+        raise SwkError("swk_stage_frames failed (%d)" % rc)
 
 
 class DevicePlanes:

@@ -25,6 +25,40 @@ STAGE_KEYS = OrderedDict([("gray", "grayscale"), ("rpca", "RPCA"), ("bilateral",
                           ("thresh", "thresh_15"), ("opened", "opened"), ("labels", "cc_labeling")])
 
 
+class _Cut(tuple):
+    """(frame, bbox, min_seg_size, crop_region) of a segment image that has not been cut yet."""
+    __slots__ = ()
+
+
+def window_segments(segs, nseg, slots, min_seg_size, crop_region, batch=None):
+    """Segment objects of a whole batch_run at once: slots = the Frame objects in the batch's frame order; segs / nseg = its
+    region records.  The same attributes Segment.__init__ sets (label, bbox, centroid = sum / area in float64, area), made
+    from whole-batch arrays instead of one record at a time; segment images are cut when first read."""
+    F, cap = segs.shape
+    live = segs[np.arange(cap)[None, :] < nseg[:, None]]              # frame order, ascending label
+    area = live["area"]
+    fa = area.astype(np.float64)
+    rows = zip(live["label"].tolist(), live["r0"].tolist(), live["c0"].tolist(), live["r1"].tolist(), live["c1"].tolist(),
+               (live["sum_r"].astype(np.float64) / fa).tolist(), (live["sum_c"].astype(np.float64) / fa).tolist(), area.tolist())
+    new = Segment.__new__
+    k = 0
+    for slot, count in zip(slots, nseg.tolist()):
+        number, stamp, frame = slot.frame_number, slot.timestamp, slot.frame
+        out = []
+        for _ in range(count):
+            lab, r0, c0, r1, c1, cy, cx, ar = next(rows)
+            s = new(Segment)
+            bbox = (r0, c0, r1, c1)
+            s.__dict__ = {"parent_frame_number": number, "parent_timestamp": stamp, "_image": _Cut((frame, bbox, min_seg_size, crop_region)),
+                          "segment_history": [], "status": None, "label": lab, "bbox": bbox, "centroid": (cy, cx), "area": ar,
+                          "_batch": batch, "_index": k}
+            if batch is None:
+                del s.__dict__["_batch"], s.__dict__["_index"]
+            out.append(s)
+            k += 1
+        slot.segments = out
+
+
 class Segment:
     """data_structures.py:16-30.  The reference copies every public regionprops attribute
     (about 9 ms per segment); only label/bbox/centroid/area are ever read downstream
@@ -45,7 +79,10 @@ class Segment:
     @property
     def segment_image(self):
         im = self._image
-        if callable(im):
+        if type(im) is _Cut:                 # (frame, bbox, min_seg_size, crop_region): the view is made on first read
+            r0, r1, c0, c1 = img.segment_crop_box(im[1], im[0].shape, im[2], im[3])
+            im = self._image = im[0][r0:r1, c0:c1]
+        elif callable(im):
             im = self._image = im()
         return im
 
@@ -229,8 +266,7 @@ class FrameQueue(deque):
         shape = (len(frames), yb - ya, xb - xa) + frames[0].shape[2:]
         if self._staging is None or self._staging.shape != shape:
             self._staging = _lib.pinned_empty(shape, np.uint8, device=self.device)      # page-locked: the upload is one DMA
-        for i, f in enumerate(frames):
-            self._staging[i] = f[ya:yb, xa:xb]
+        _lib.stage_frames(frames, ya, yb, xa, xb, self._staging)
         return self._staging, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
 
     def segment_queue(self, min_seg_size, crop_region):
@@ -263,15 +299,7 @@ class FrameQueue(deque):
             for key, name in STAGE_KEYS.items():
                 for i, slot in enumerate(self):
                     slot.processed_frames[name] = (lambda k=key, i=i, p=planes: p.read(k, i))
-        k = 0
-        for i, slot in enumerate(self):
-            props = img.regionprops_from_records(res["segs"][i, :nseg[i]])
-            slot.segments = segs = [Segment(rp, slot.frame_number, slot.timestamp, img.segment_image_getter(rp, slot.frame, min_seg_size, crop_region))
-                                    for rp in props]
-            if batch is not None:
-                for s in segs:
-                    s._batch, s._index = batch, k
-                    k += 1
+        window_segments(res["segs"], nseg, list(self), tuple(min_seg_size), crop_region, batch)
 
 
 def _margin_rect(frame_shape, crop_region, min_seg_size):
@@ -297,11 +325,12 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(first.shape, crop_region, min_seg_size)
     ctx = _lib.default_context(device)
     stack = ctx.staging((len(windows) * n, yb - ya, xb - xa) + first.shape[2:])
-    for w, (frames, _, _) in enumerate(windows):
+    ordered = []
+    for frames, _, _ in windows:
         if len(frames) != n:
             raise ValueError("every window needs the same number of frames")
-        for k, f in enumerate(frames):                       # queue index 0 = newest = last frame read (:134)
-            stack[w * n + (n - 1 - k)] = f[ya:yb, xa:xb]
+        ordered.extend(frames[::-1])                         # queue index 0 = newest = last frame read (:134)
+    _lib.stage_frames(ordered, ya, yb, xa, xb, stack)
     res = ctx.batch_run(stack, len(windows), n, crop=(x0 - xa, y0 - ya, x1 - x0, y1 - y0), params=params, stages=())
     nseg = res["nseg"]
     if np.any(nseg > res["segs"].shape[1]):
@@ -309,19 +338,12 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     batch = WindowBatch(ctx, ctx.generation, int(nseg.sum()), min_seg_size) if stack.ndim == 4 else None
     if batch is not None and classifier is not None:
         batch.launch(classifier)
-    starts = np.concatenate([[0], np.cumsum(nseg)]).tolist()
+    slots = [None] * (len(windows) * n)
     out = []
     for w, (frames, numbers, stamps) in enumerate(windows):
-        popped = []
-        for k in range(n):                                   # oldest first
-            slot = w * n + (n - 1 - k)
-            fr = Frame(frames[k], numbers[k], stamps[k])
-            props = img.regionprops_from_records(res["segs"][slot, :nseg[slot]])
-            fr.segments = [Segment(rp, numbers[k], stamps[k], img.segment_image_getter(rp, frames[k], min_seg_size, crop_region))
-                           for rp in props]
-            if batch is not None:
-                for j, sg in enumerate(fr.segments, starts[slot]):
-                    sg._batch, sg._index = batch, j
-            popped.append(fr)
+        popped = [Frame(frames[k], numbers[k], stamps[k]) for k in range(n)]          # oldest first
+        for k, fr in enumerate(popped):
+            slots[w * n + (n - 1 - k)] = fr
         out.append(popped)
+    window_segments(res["segs"], nseg, slots, tuple(min_seg_size), crop_region, batch)
     return out

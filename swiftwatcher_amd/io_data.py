@@ -41,7 +41,8 @@ def _round_us(ns):
 
 def frame_timestamp_ns(frame_number, fps):
     """io_video.py:74-82: nanoseconds after midnight of the timestamp the reference's reader gives a frame."""
-    return int(_round_us(_timedelta_ns(frame_number / fps, NS)))
+    q, r = divmod(_timedelta_ns(frame_number / fps, NS), 1000)          # _round_us on one value, in plain integers
+    return (q + (1 if r > 500 or (r == 500 and q & 1) else 0)) * 1000
 
 
 def create_empty_table(fps, start, end):

@@ -238,6 +238,7 @@ class CroppedSqueezeNet10:
             else:
                 live.append(None)
         self._buf, self._cap = (bufs, live), batch
+        self.version = getattr(self, "version", 0) + 1          # new addresses: captured graphs of the old ones are void
         return self._buf
 
     @torch.no_grad()
@@ -417,6 +418,7 @@ class CroppedSqueezeNet10:
             if kind == "pool":
                 aux["pool_out"].append(buf(tile.shape[1], (tile.shape[2] - 3) // 2 + 1))
         self._aux, self._aux_cap = aux, batch
+        self.version = getattr(self, "version", 0) + 1
         return aux
 
 
@@ -480,6 +482,9 @@ class SegmentClassifier:
         # device-side input buffers of scores_from_device / predict_last_batch: two slots, each with the event of the last forward
         # that read it (a slot is handed to the library's stream again only after that event)
         self._slots = None
+        self._graphs = {}
+        self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
+        self._graph_error = None
 
     def preprocess(self, segment_images, window=False):
         """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device, or with
@@ -524,8 +529,34 @@ class SegmentClassifier:
                 return self.cropped(x) if self.cropped is not None else self.model(x)
         return self.cropped(x) if self.cropped is not None else self.model(x)
 
-    def _run(self, x, k):
-        """Scores of the first k rows of x (x has _bucket(k) rows)."""
+    def _forward_graphed(self, x):
+        """A window's worth of segments (<= 512 rows) is some thirty kernels of a few microseconds each: launched one by one from
+        Python they cost more host time than GPU time.  The forward on a persistent input slot is captured once per (slot, rows) as a
+        HIP graph and replayed with one launch.  Anything that goes wrong while capturing switches this off for the classifier."""
+        key = (x.data_ptr(), int(x.shape[0]), getattr(self.cropped, "version", 0))
+        entry = self._graphs.get(key)
+        if entry is None:
+            try:
+                self._forward(x)                                            # kernel attributes, persistent tiles, library handles
+                torch.cuda.current_stream(self.device).synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._forward(x)
+                if len(self._graphs) >= 24:
+                    self._graphs.clear()
+                entry = self._graphs[key] = (graph, out)
+            except Exception as exc:                                        # noqa: BLE001
+                self._use_graphs = False
+                self._graph_error = repr(exc)
+                torch.cuda.synchronize(self.device)
+                return self._forward(x)
+        entry[0].replay()
+        return entry[1]
+
+    def _run(self, x, k, persistent=False):
+        """Scores of the first k rows of x (x has _bucket(k) rows).  persistent: x is one of the classifier's own input slots."""
+        if persistent and self._use_graphs and x.shape[0] <= 512 and self.cropped is not None and not self.timing:
+            return self._forward_graphed(x)[:k]
         if self.timing and self.device.type == "cuda":
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -595,7 +626,7 @@ class SegmentClassifier:
         while first < total:
             slot = i & 1
             k = min(bs, total - first)
-            scores.append(self._run(xb[slot][:self._bucket(k)], k).clone())     # rows past k hold an earlier chunk: scored, dropped
+            scores.append(self._run(xb[slot][:self._bucket(k)], k, persistent=True).clone())     # rows past k hold an earlier chunk: scored, dropped
             frames_of.append(fb[slot][:k].clone())
             done[slot] = torch.cuda.Event()
             done[slot].record(torch.cuda.current_stream(self.device))

@@ -648,7 +648,7 @@ def test_framequeue_stage_images_stay_on_the_gpu_until_read(orc):
             for name, key in names.items():
                 np.testing.assert_array_equal(f.get_processed_frame(name), ref[key][pos], err_msg=name)
             assert not callable(OrderedDict.__getitem__(f.processed_frames, "opened"))        # resolved values are kept
-    del kept, frames_of_window, f
+    del kept, frames_of_window, f, raw
     import gc
     gc.collect()
     assert len(ctx._plane_pool[pool_key]) == 2                             # handed back, ready for the next windows
