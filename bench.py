@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
     ap.add_argument("--host-input", action="store_true", help="(default at N = 1) kept for compatibility: pcie_inclusive is part of the line")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in / count_loop / pcie_inclusive sub-results (kernel A/Bs)")
-    ap.add_argument("--loop-windows", type=int, default=16, help="21-frame windows of the count_loop clip (1080p frames in host memory: 130 MB each)")
+    ap.add_argument("--loop-windows", type=int, default=24, help="21-frame windows of the count_loop clip (1080p frames in host memory: 130 MB each)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher rehearsal without any GPU work: the ranks join the process group (SWK_DIST_BACKEND, gloo on CPU-only "
                          "hosts), run the barrier / max-over-ranks clock / count gather around EMPTY steps and print the line with value 0")
@@ -238,8 +238,8 @@ def reference_call_pattern(ctx_device, clf, args, geo):
     roi_mask[100:, 42:382] = 255
     loop = {}
     for name, kw in (("reference_pattern", dict()), ("windows_per_call_8", dict(windows_per_call=8))):
-        for timed in (False, True):                                      # first run = warm-up (shapes, pools, MIOpen find)
-            reader = ArrayReader(flist if timed else flist[:4 * n])
+        for timed in (False, True):                                      # first run = warm-up (staging buffers, tile pools, graphs)
+            reader = ArrayReader(flist)
             t0 = time.perf_counter()
             events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=clf, keep_stages=True, **kw)
             dt = time.perf_counter() - t0

@@ -232,7 +232,9 @@ int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, i
  * whole buffer) lets boxes grow into that margin like extract_segment_images grows them into the full frame
  * (image_filtering.py:338-369): with a margin of min_seg_size / 2 (or up to the frame's edge) every crop equals the
  * reference's.  This is how SegmentClassifier scores all segments of a FrameQueue window in one batch at the window's
- * first classifier call (__main__.py:84-85).  SWK_ERR_STALE when another call has reused the buffers since. */
+ * first classifier call (__main__.py:84-85).  SWK_ERR_STALE when another call has reused the buffers since.
+ * *total is read as well: >= 0 = the caller's own count of the batch's segments (sum of min(nseg, seg_cap) of that batch_run's
+ * host output; checked, and it saves the round trip that fetches the count from the device), -1 = not known. */
 int32_t swk_segment_inputs_last(swk_ctx *ctx, int32_t min_h, int32_t min_w, const float mean[3], const float std_[3],
                                 int32_t pad, int32_t channels_last, int32_t first, int32_t net_cap, float *net,
                                 int32_t *seg_frame, int32_t *total, int32_t *skipped);

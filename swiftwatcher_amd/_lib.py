@@ -513,13 +513,13 @@ class Context:
         return total.value, skipped.value
 
     def segment_inputs_last(self, generation, mean, std, net_ptr, net_cap, first=0, pad=8, min_seg_size=(24, 24),
-                            seg_frame_ptr=None, channels_last=False):
+                            seg_frame_ptr=None, channels_last=False, known_total=-1):
         """swk_segment_inputs_last: the same for the batch this context ran LAST (its own device copy of the frames, its own
         region records).  generation = Context.generation right after that batch_run: raises StaleBatch when the context
         has run another batch since (the buffers hold something else now).  Returns (total, skipped)."""
         m = np.asarray(mean, np.float32)
         s = np.asarray(std, np.float32)
-        total = ctypes.c_int32(0)
+        total = ctypes.c_int32(int(known_total))
         skipped = ctypes.c_int32(0)
         with self._lock:                 # nothing may slip in between the generation test and the call
             if generation != self.generation:

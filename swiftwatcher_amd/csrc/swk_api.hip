@@ -75,6 +75,7 @@ struct swk_ctx {
         const uint8_t *frames = nullptr;
         int64_t fs = 0, rs = 0;
         int nwin = 0, n = 0, Hc = 0, Wc = 0, x0 = 0, y0 = 0, frame_h = 0, frame_w = 0, cap = 0;
+        int total = -1;          // segments of the batch (regions beyond cap not counted), when nseg was copied to the host
         const swk_segment *segs = nullptr;
         const int32_t *nseg = nullptr;
     } last;
@@ -453,7 +454,7 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
 int segment_inputs_impl(swk_ctx *ctx, const uint8_t *frames, int64_t fs, int64_t rs, int F, int x0, int y0, int frame_h, int frame_w,
                         const swk_segment *segs, const int32_t *nseg, int seg_cap, int min_h, int min_w, const float *mean,
                         const float *std_, int pad, bool nhwc, int first, int net_cap, float *net, int32_t *seg_frame, int32_t *total,
-                        int32_t *skipped)
+                        int32_t *skipped, int known_total = -1)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -462,9 +463,11 @@ int segment_inputs_impl(swk_ctx *ctx, const uint8_t *frames, int64_t fs, int64_t
     int32_t *dskip = doffs + F + 1;
     HIPCHK(ctx, hipMemsetAsync(dskip, 0, 4, s));
     launch_segment_prefix(s, nseg, F, seg_cap, doffs);
-    int32_t tot = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&tot, doffs + F, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    int32_t tot = known_total;
+    if (tot < 0) {          // the caller does not know how many segments the batch holds: one round trip
+        HIPCHK(ctx, hipMemcpyAsync(&tot, doffs + F, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    }
     *total = tot;
     if (skipped) *skipped = 0;
     int count = tot - first;
@@ -863,6 +866,11 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         lb.nwin = in->nwin; lb.n = in->n; lb.Hc = H; lb.Wc = W; lb.x0 = x0; lb.y0 = y0;
         lb.frame_h = (int)(fs / rs); lb.frame_w = (int)(rs / 3);
         lb.segs = dsegs; lb.nseg = dnseg; lb.cap = cap;
+        lb.total = -1;
+        if (!dev_out && out->nseg) {
+            lb.total = 0;
+            for (int f = 0; f < F; ++f) lb.total += out->nseg[f] < cap ? out->nseg[f] : cap;
+        }
         lb.valid = true;
     }
     return gather_iters(ctx, dev_out ? nullptr : out->iters, dev_out ? out->iters : nullptr);
@@ -1071,8 +1079,10 @@ int32_t swk_segment_inputs_last(swk_ctx *ctx, int32_t min_h, int32_t min_w, cons
         return fail(ctx, SWK_ERR_ARG, "bad argument");
     const swk_ctx::LastBatch &lb = ctx->last;
     if (!lb.valid) return fail(ctx, SWK_ERR_STALE, "no batch with BGR frames and region records is held by the context any more");
+    const int known = *total >= 0 && lb.total >= 0 ? lb.total : -1;          // the batch's own count, when its nseg went to the host
+    if (known >= 0 && *total != known) return fail(ctx, SWK_ERR_ARG, "*total does not match the batch");
     return segment_inputs_impl(ctx, lb.frames, lb.fs, lb.rs, lb.nwin * lb.n, lb.x0, lb.y0, lb.frame_h, lb.frame_w, lb.segs, lb.nseg, lb.cap,
-                               min_h, min_w, mean, std_, pad, channels_last != 0, first, net_cap, net, seg_frame, total, skipped);
+                               min_h, min_w, mean, std_, pad, channels_last != 0, first, net_cap, net, seg_frame, total, skipped, known);
 }
 
 int32_t swk_classifier_input(swk_ctx *ctx, const uint8_t *crops, int64_t crops_bytes, const int64_t *offsets,

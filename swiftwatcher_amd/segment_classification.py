@@ -655,7 +655,7 @@ class SegmentClassifier:
         raises _lib.StaleBatch when the context has moved on."""
         def cut(net_ptr, frame_ptr, cap, first, pad, nhwc):
             return ctx.segment_inputs_last(generation, IMAGENET_MEAN, IMAGENET_STD, net_ptr, cap, first=first, pad=pad,
-                                           min_seg_size=min_seg_size, seg_frame_ptr=frame_ptr, channels_last=nhwc)
+                                           min_seg_size=min_seg_size, seg_frame_ptr=frame_ptr, channels_last=nhwc, known_total=total)
         scores, _ = self._scores_device(cut)
         if scores.shape[0] != total:
             raise RuntimeError("the device holds %d segments, the window has %d" % (scores.shape[0], total))
