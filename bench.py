@@ -290,7 +290,7 @@ def main():
     F, P = nwin * n, Hc * Wc
 
     # ---- synthetic stream, resident in HBM (each rank its own "videos": weak scaling) ----
-    frames = synthetic.roi_stream_torch(dev, F, Hc, Wc, seed=20190816 + 1000 * rank,
+    frames = synthetic.roi_stream_torch(dev, F, Hc, Wc, seed=20190816 + 1000 * rank, birds=geo["birds"],
                                         bird_len=geo["bird_len"], bird_wid=geo["bird_wid"])
     labels = torch.empty((F, Hc, Wc), dtype=torch.uint8, device=dev)
     seg_cap = 64
@@ -537,7 +537,7 @@ def main():
                                     % ("full 224x224 network" if args.full_network else "receptive-field cropped",
                                        kept_total[1], kept_total[0])) if clf else "off (--no-classify)",
                        "parallelism": "windows sharded per GPU, no data-path collective"},
-            "redo_batches": int(redo),
+            "redo_batches": int(redo), "guard_windows": int(ctx.guard_windows),
             "per_rank": [{"rank": r, "frames": int(table[r, 2]), "frames_per_s": round(float(table[r, 2]) / max(float(rank_ms[r]) * 1e-6, 1e-9), 1),
                           "kept_or_found": int(table[r, 0]), "ialm_iterations": int(table[r, 1])} for r in range(world)],
             "launched_by": "bench.py" if os.environ.get("SWK_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),

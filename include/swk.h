@@ -351,6 +351,12 @@ int32_t swk_set_sparse_speculation(swk_ctx *ctx, double factor);
  * stop; a window where it cannot is rerun like above.  After a rerun the guess that failed stays off for the next
  * 64 batches of the context (the windows of one video behave alike). */
 int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
+/* M-state pass only: the stopping test ||Z||_F < tol ||X||_F (image_filtering.py:297) is made on a float32 sum over a binary16 copy
+ * of Y/mu (relative error about 1e-6).  A window whose ratio ||Z|| / (tol ||X||) comes within `rel` of 1 (default 1e-3; 0 = off) is
+ * not decided on that number: it is run again, alone, by the A/Y-state pass, whose norm is formed in float64 like the reference's.
+ * swk_prof_guard_windows counts those windows. */
+int32_t swk_set_norm_guard(swk_ctx *ctx, double rel);
+int32_t swk_prof_guard_windows(swk_ctx *ctx, int64_t *windows);
 /* M-state pass only: 1 (default) = statistics and the first iteration's Gram matrix come from one read of X on the
  * integer matrix cores wherever the first shrinkage provably removes nothing; 0 = always the f64 start pass. */
 int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on);

@@ -93,6 +93,8 @@ _SIGS = {
     "swk_last_integer_start_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_last_eig_sweeps": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_set_norm_guard": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_prof_guard_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_nhwc_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6),
@@ -319,6 +321,15 @@ class Context:
 
     def set_integer_start(self, on):
         self._check(self._lib.swk_set_integer_start(self._h, int(bool(on))))
+
+    def set_norm_guard(self, rel):
+        self._check(self._lib.swk_set_norm_guard(self._h, float(rel)))
+
+    @property
+    def guard_windows(self):
+        v = ctypes.c_int64(0)
+        self._check(self._lib.swk_prof_guard_windows(self._h, ctypes.byref(v)))
+        return v.value
 
     def set_norm_speculation(self, factor):
         self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))

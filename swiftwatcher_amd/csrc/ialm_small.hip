@@ -61,7 +61,14 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
             if (k >= 2) u += 128 + (st.ru ? 32 : 2);
             st.pass_b16 += u;
         }
-        if (!full && ratio < tol && k < maxiter) {
+        // M-state pass: the norm is a float32 sum over a binary16 copy of Y/mu (relative error about 1e-6).  Inside the guard
+        // band the comparison with tol is not trusted: the window stops here and the host runs it again with the float64 norm.
+        const double band = b.guard > 0.0 ? b.guard : 0.0;
+        if (full && band > 0.0 && k < maxiter && fabs(ratio / tol - 1.0) < band) {
+            if (tid == 0) { st.iter = k; st.done = 1; st.redo |= 4; atomicSub(b.active, 1); }
+            return false;
+        }
+        if (!full && ratio < tol * (1.0 + band) && k < maxiter) {
             // the bound cannot rule out that this iteration is the last: give the window up, the host runs the
             // batch again with every norm formed
             if (tid == 0) { st.iter = k; st.done = 1; st.redo |= 2; atomicSub(b.active, 1); }

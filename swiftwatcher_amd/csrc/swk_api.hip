@@ -49,6 +49,8 @@ struct swk_ctx {
     int ialm_variant = 0;
     int pass_tune = 0;             // k-step-templated pass: bit 0 priority, bit 1 stagger for the odd hardware wave slot
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
+    double norm_guard = 1e-3;      // M-state pass: |ratio / tol - 1| below this does not decide (the window is rerun with the f64 norm)
+    int64_t guard_windows = 0;     // windows rerun for that reason
     int64_t redo_batches = 0;
     int last_eig_sweeps = 0;       // largest IalmWin::sweeps of the last batch (Newton-Schulz iterations, or 100 + Jacobi sweeps)
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
@@ -259,14 +261,14 @@ int ensure_ccl(swk_ctx *ctx, int F, int H, int W, CclBuffers *b)
 // ---- IALM driver ----------------------------------------------------------------------
 int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmbda, double tol, int maxiter,
              bool want_A, bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/,
-             bool speculate = true)
+             bool speculate = true, int force_variant = 0)
 {
     if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     // auto: the M-state pass (k-step-templated, 21 B/element) unless the caller wants the f64 low-rank / sparse matrices,
     // which only the A/Y-state pass (v2, 34 B/element) materialises
-    int variant = ctx->ialm_variant;
+    int variant = force_variant ? force_variant : ctx->ialm_variant;
     if (variant == 0) variant = 4;
     if (variant >= 3 && (want_A || want_E)) variant = 2;
     const bool mstate = variant >= 3;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
@@ -291,6 +293,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         b.U = (uint16_t *)b.Y;               // binary16 planes in the Y slot
         b.spec = (speculate && ctx->sparse_backoff == 0) ? ctx->sparse_spec : 0.0;
         b.nspec = (speculate && ctx->norm_backoff == 0) ? ctx->norm_spec : 0.0;
+        b.guard = ctx->norm_guard;
         if (speculate) {
             if (ctx->sparse_backoff > 0) ctx->sparse_backoff -= 1;
             if (ctx->norm_backoff > 0) ctx->norm_backoff -= 1;
@@ -411,19 +414,40 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // everything after the IALM runs on the main stream: join the side streams
     if (ngroups > 1) for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
     if (mstate) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
-    if (mstate && (b.spec > 0.0 || b.nspec > 0.0)) {
+    if (mstate && (b.spec > 0.0 || b.nspec > 0.0 || b.guard > 0.0)) {
         // did any window stop right after a pass that had its sparse-image stores switched off?
         std::vector<IalmWin> hw(nwin);
         HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
         int redo = 0;
         for (int w = 0; w < nwin; ++w) redo |= hw[w].redo;
-        if (redo) {
+        if (redo & 3) {
             // windows of one video behave alike: a guess that failed stays off for the next batches
             ctx->redo_batches += 1;
             if (redo & 1) ctx->sparse_backoff = 64;
             if (redo & 2) ctx->norm_backoff = 64;
             return run_ialm(ctx, dX, nwin, n, P, lmbda, tol, maxiter, want_A, want_E, dS, h_iters, d_iters, false);
+        }
+        if (redo & 4) {
+            // windows whose float32 stopping norm fell inside the guard band: each of them alone through the A/Y-state pass (norm in
+            // float64, statement by statement the reference's :293-297); its sparse image lands in the window's planes of dS, its
+            // state struct replaces the window's entry (iteration count, diagnostics)
+            for (int w = 0; w < nwin; ++w) {
+                if (!(hw[w].redo & 4)) continue;
+                ctx->guard_windows += 1;
+                int rc1 = run_ialm(ctx, dX + (size_t)w * n * P, 1, n, P, lmbda, tol, maxiter, false, false, dS + (size_t)w * n * P, nullptr,
+                                   nullptr, false, 2);
+                if (rc1) return rc1;
+                IalmWin one;
+                HIPCHK(ctx, hipMemcpyAsync(&one, ctx->last_win, sizeof(IalmWin), hipMemcpyDeviceToHost, s));
+                HIPCHK(ctx, hipStreamSynchronize(s));
+                one.pass_b16 = hw[w].pass_b16;          // the roofline books the M-state passes the window did run
+                one.int_gram = hw[w].int_gram;
+                hw[w] = one;
+            }
+            // (the slots may have moved: NEED only grows them, and SL_WIN was sized for nwin before)
+            HIPCHK(ctx, hipMemcpyAsync(b.win, hw.data(), (size_t)nwin * sizeof(IalmWin), hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
         }
     }
     ctx->last_win = b.win;
@@ -675,6 +699,18 @@ int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on)
 {
     if (!ctx) return SWK_ERR_ARG;
     ctx->use_gram8 = on ? 1 : 0;
+    return SWK_OK;
+}
+int32_t swk_set_norm_guard(swk_ctx *ctx, double rel)
+{
+    if (!ctx || !(rel >= 0.0) || rel >= 1.0) return SWK_ERR_ARG;
+    ctx->norm_guard = rel;
+    return SWK_OK;
+}
+int32_t swk_prof_guard_windows(swk_ctx *ctx, int64_t *windows)
+{
+    if (!ctx || !windows) return SWK_ERR_ARG;
+    *windows = ctx->guard_windows;
     return SWK_OK;
 }
 int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor)

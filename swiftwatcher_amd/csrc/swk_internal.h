@@ -65,7 +65,9 @@ struct IalmWin {
     int sweeps;                    // Jacobi sweeps used by the last eigen solve (diagnostic)
     int ws, ws_prev;               // M-state pass: did / does the pass of this (the previous) iteration write the sparse image
     int redo;                      // the window has to be run again: bit 0 = the last iteration's sparse image was not
-                                   // written, bit 1 = a partial norm could not rule out that an iteration was the last
+                                   // written, bit 1 = a partial norm could not rule out that an iteration was the last,
+                                   // bit 2 = the float32 stopping norm fell inside the guard band around the tolerance: this
+                                   // window alone is run again by the A/Y-state pass (float64 norm, like the reference)
     int ru, wu;                    // M-state pass: this pass reads / writes ALL of U (else frames 0..3 only)
     double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
     int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
@@ -89,6 +91,8 @@ struct IalmBuffers {
     double spec;                   // M-state pass: sparse image written only once ||Z|| < spec * tol * ||X|| (<= 0: always)
     int use_gram8;                 // k_gram_u8 ran: k_ialm_init decides per window whether its result stands
     double nspec;                  // M-state pass: ||Z|| formed every other iteration while above nspec * tol * ||X|| (<= 0: always)
+    double guard;                  // M-state pass: relative half-width of the band around tol in which the float32 norm does
+                                   // not decide (<= 0: off; the A/Y-state pass forms the norm in float64 and needs none)
     int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
     int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows

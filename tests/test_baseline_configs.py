@@ -94,6 +94,32 @@ def test_reference_fixture_at_workload_size(ctx, orc, golden_dir, name):
     assert sha256(np.ascontiguousarray(ctx.rpca_epilogue(E).T.reshape(n, H, W))) == str(g["sparse_sha256"])
 
 
+@pytest.mark.parametrize("name", ["ialm_47x94x21_s301", "ialm_47x94x21_s305", "ialm_47x94x21_s302", "ialm_47x94x21_s303",
+                                  "ialm_47x94x21_s304", "ialm_107x214x21_s311", "ialm_107x214x21_s312"])
+def test_reference_fixtures_around_the_start_switch(ctx, golden_dir, name):
+    """Config 1's window size (94 x 47 x 21) on both sides of the switch between the integer start and the f64 start pass -- s301 and
+    s305 sit 0.3 % and 0.2 % from it -- and two windows at 214 x 107 x 21, all produced by the REFERENCE's own rpca / IALM
+    (oracle/make_goldens_r3.py): which start runs is the host-side statement of the rule, iteration count and the uint8 sparse
+    image equal the reference's, A and E on the sampled rows <= 1e-5."""
+    from test_oracle_golden import seeded_frames
+    from oracle.scenes import sha256
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    frames = seeded_frames(g)
+    n, H, W = frames.shape
+    integer = bool(_expected_integer_start(frames))
+    assert integer == (float(g["switch_ratio"]) <= 1.0)
+    res = ctx.batch_run(frames, 1, n, stages=("gray", "rpca"))
+    assert ctx.last_integer_start_windows == int(integer)
+    assert int(res["iters"][0]) == int(g["iters"])
+    assert sha256(res["rpca"]) == str(g["sparse_sha256"])
+    np.testing.assert_array_equal(res["rpca"].reshape(n, -1).astype(np.int64).sum(axis=1), g["sparse_frame_sums"])
+    A, E, iters = ctx.ialm(frames.reshape(n, H * W))
+    assert iters == int(g["iters"])
+    rows = g["rows"]
+    np.testing.assert_allclose(A[rows], g["A_rows"], atol=ATOL_AE, rtol=0)
+    np.testing.assert_allclose(E[rows], g["E_rows"], atol=ATOL_AE, rtol=0)
+
+
 def test_config2_full_window_against_oracle(ctx, orc):
     """Config 2's unit of work from BGR input: one 424 x 212 x 64 window of the bench's own synthetic stream
     (12 birds per frame) against orc.window -- every stage image, region records, iteration count."""
@@ -219,6 +245,86 @@ def test_config3_1080p_classifier_tracker(tmp_path):
         count_b, events_b = pipeline.count_swifts(list(clip), crop_region, roi_mask, classifier=clf, windows_per_call=wpc)
         assert count_b == count and event_signature(events_b) == event_signature(events)
     _lib.default_context(0).prof_enable(False)
+
+
+_C3 = {}
+
+
+def _config3_model_pt_case(golden_dir):
+    """Config 3 "incl. model.pt CNN": 70 full 1080p frames (3 queues of 21 + one padded), 14 small faint birds per frame (5-8 x 4-6 px,
+    contrast 25-40: the one kind of synthetic blob the reference's trained weights keep a fair share of), oracle segments and crops, the
+    oracle classifier on the REFERENCE's own weights (tests/golden/classifier_model_pt.npz = model.pt's 52 tensors)."""
+    if not _C3:
+        from swiftwatcher_amd import synthetic
+        from swiftwatcher_amd import image_filtering as img
+        from oracle import classifier_ref
+        from test_classifier import _model_pt_fixture
+        corners = [(790, 620), (1130, 622)]
+        crop_region = img.generate_crop_region(corners)
+        clip = synthetic.full_frames(1081, 70, crop_region, birds=14, bird_len=(5, 8), bird_wid=(4, 6), contrast=(25, 40))[::-1].copy()
+        info = oracle_frames(clip, crop_region)
+        crops = [c for fr in info for c in fr["crops"]]
+        sd = _model_pt_fixture(golden_dir)[0]
+        scores, keep_flat = classifier_ref.classify(sd, crops)
+        margin = np.abs(scores[:, 1] - scores[:, 0])
+        assert margin.min() > 1e-3, margin.min()            # margin gate: no decision float32 summation order could flip
+        assert 0.1 * len(crops) < keep_flat.sum() < 0.5 * len(crops) and len(crops) > 800
+        keep, at = [], 0
+        for fr in info:
+            keep.append(list(keep_flat[at:at + len(fr["crops"])]))
+            at += len(fr["crops"])
+        _C3.update(corners=corners, crop_region=crop_region, clip=clip, info=info, sd=sd, keep=keep)
+    return _C3
+
+
+def test_config3_with_model_pt_weights(golden_dir):
+    """BASELINE config 3 as worded: full 1080p video, the model.pt CNN, tracking.  SegmentClassifier loads the reference's weights;
+    the counting loop (one queue per call, classifier per popped frame -- served from the window's score table) must produce the
+    events of the oracle pipeline (oracle segments -> oracle classifier on the same weights -> same tracker), and the count."""
+    from swiftwatcher_amd import pipeline
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    c = _config3_model_pt_case(golden_dir)
+    roi_mask = np.zeros((212, 424), np.uint8)
+    roi_mask[100:, 42:382] = 255
+    ref_events = track(c["info"], roi_mask, c["keep"])
+    assert event_signature(ref_events) != event_signature(track(c["info"], roi_mask))        # the classifier changes the outcome
+    clf = SegmentClassifier.from_state_dict(c["sd"])
+    launches = []
+    inner = clf.predict_last_batch
+    clf.predict_last_batch = lambda *a, **k: (launches.append(1), inner(*a, **k))[1]
+    count, events = pipeline.count_swifts(list(c["clip"]), c["crop_region"], roi_mask, classifier=clf)
+    assert event_signature(events) == event_signature(ref_events)
+    assert count == ec.count_swifts(ref_events)
+    assert len(launches) == 4                       # one device-resident scoring batch per queue-ful, not one per frame
+    count_b, events_b = pipeline.count_swifts(list(c["clip"]), c["crop_region"], roi_mask, classifier=clf, windows_per_call=2)
+    assert count_b == count and event_signature(events_b) == event_signature(events)
+
+
+def test_counting_loop_from_corners(golden_dir):
+    """The loop as __main__.py:62-63 starts it: crop region AND ROI mask generated from the video's first frame and the two chimney
+    corners (generate_regions inside count_swifts), against the oracle pipeline with oracle/roi_mask_ref.py's mask -- without and
+    with the model.pt classifier."""
+    from swiftwatcher_amd import pipeline
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import roi_mask_ref
+    c = _config3_model_pt_case(golden_dir)
+    mask_ref = roi_mask_ref.roi_mask(c["clip"][0], c["corners"], c["crop_region"])
+    crop_region, mask, _ = img.generate_regions(c["clip"][0], c["corners"])
+    assert crop_region == c["crop_region"]
+    np.testing.assert_array_equal(mask, mask_ref)
+    assert 2000 < int((mask == 255).sum()) < 20000
+    ref_events = track(c["info"], mask_ref)
+    count, events = pipeline.count_swifts(list(c["clip"]), corners=c["corners"])
+    assert event_signature(events) == event_signature(ref_events) and count == ec.count_swifts(ref_events)
+    assert len(events) >= 3
+    ref_events_clf = track(c["info"], mask_ref, c["keep"])
+    clf = SegmentClassifier.from_state_dict(c["sd"])
+    count_c, events_c = pipeline.count_swifts(list(c["clip"]), corners=c["corners"], classifier=clf)
+    assert event_signature(events_c) == event_signature(ref_events_clf) and count_c == ec.count_swifts(ref_events_clf)
+    assert event_signature(events_c) != event_signature(events)
 
 
 def test_config5_4k_roi_window_from_bgr(ctx, orc):

@@ -344,6 +344,64 @@ def test_mstate_pass_every_kstep_count(orc):
         c.close()
 
 
+def test_short_windows_at_config1_element_count_against_oracle(orc):
+    """n = 3 ... 9 frames at 9e4 to 1e5 elements per window -- the element count of BASELINE config 1's window (94 x 47 x 21 =
+    92.8 k), inside the range the k-step test above leaves out -- against the ORACLE (not only kernel against kernel):
+    iteration count and the uint8 sparse image, for the default k-step kernel, the plain tile loop and the block kernel."""
+    from swiftwatcher_amd import _lib, synthetic
+    ctxs = {}
+    for key, variant in {"default": 0, "plain": 5, "block": 3}.items():
+        c = _lib.Context(0)
+        c.set_ialm_variant(variant)
+        ctxs[key] = c
+    for n, Hc, Wc in ((3, 150, 208), (4, 133, 175), (5, 120, 160), (7, 101, 133), (9, 90, 117)):
+        assert 9.0e4 <= n * Hc * Wc <= 1.0e5
+        roi = synthetic.roi_window(1300 + n, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
+        ref = orc.window(roi)
+        gray = ref["gray"].reshape(n, -1).T
+        k_ref = orc.ialm(gray, return_iters=True)[2]
+        for key, c in ctxs.items():
+            res = c.batch_run(roi, 1, n, stages=("rpca", "labels"))
+            assert int(res["iters"][0]) == k_ref, "%s n=%d: %d iterations, oracle %d" % (key, n, int(res["iters"][0]), k_ref)
+            np.testing.assert_array_equal(res["rpca"], ref["rpca"], err_msg="%s n=%d" % (key, n))
+            np.testing.assert_array_equal(res["labels"], ref["labels"], err_msg="%s n=%d" % (key, n))
+    for c in ctxs.values():
+        c.close()
+
+
+def test_stopping_decision_guard_band(orc):
+    """The M-state pass forms the stopping norm ||Z||_F in float32 from a binary16 copy of Y/mu (relative error about 1e-6).  A
+    window whose ratio ||Z|| / (tol ||X||) lands within the guard band of 1 (default 1e-3) is not decided on that number: it is
+    run again by the A/Y-state pass, which forms the norm in float64 like the reference (image_filtering.py:293-297).  Forced here
+    with a band of 0.9 (every window's stopping iteration falls inside): outputs and iteration counts are unchanged, and the
+    reruns are counted."""
+    from swiftwatcher_amd import synthetic, _lib
+    ctx = _lib.Context(0)                        # the default (M-state) pass; the parametrised fixture runs the A/Y-state kernels
+    n, Hc, Wc = 21, 64, 96
+    roi = np.concatenate([synthetic.roi_window(2100 + w, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6)) for w in range(3)])
+    base = ctx.batch_run(roi, 3, n)
+    assert ctx.guard_windows == 0
+    ctx.set_norm_guard(0.9)
+    try:
+        forced = ctx.batch_run(roi, 3, n)
+        assert ctx.guard_windows == 3
+    finally:
+        ctx.set_norm_guard(1e-3)
+    np.testing.assert_array_equal(forced["iters"], base["iters"])
+    for key in ("rpca", "bilateral", "thresh", "opened", "labels"):
+        np.testing.assert_array_equal(forced[key], base[key], err_msg=key)
+    assert forced["segs"].tobytes() == base["segs"].tobytes()
+    for w in range(3):
+        ref = orc.window(np.ascontiguousarray(roi[w * n:(w + 1) * n]))
+        np.testing.assert_array_equal(forced["rpca"][w * n:(w + 1) * n], ref["rpca"])
+    # how often the default band fires on ordinary windows: a handful of percent at most
+    many = np.concatenate([synthetic.roi_window(2200 + w, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6)) for w in range(24)])
+    before = ctx.guard_windows
+    ctx.batch_run(many, 24, n, stages=())
+    assert ctx.guard_windows - before <= 3
+    ctx.close()
+
+
 def test_duplicated_last_frame_and_null_padding(ctx, orc):
     """The last window of every video: real frames, ONE duplicate of the last real frame (io_video.py:51-53 re-delivers
     it when the frame one past the end is requested) and null frames (io_video.py:40-44).  Two equal columns make M

@@ -60,6 +60,10 @@ IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64
 # the BASELINE workload sizes: inputs regenerated from the seed (oracle/scenes.py), outputs of the reference stored as
 # iteration count, sha256 of the sparse image and A / E on sampled pixel rows (oracle/make_goldens_r2.py)
 SEEDED_CASES = ["ialm_212x424x21_seeded", "ialm_212x424x64_seeded", "ialm_425x850x21_seeded"]
+# round 3 (oracle/make_goldens_r3.py): config 1's window size on both sides of -- two of them within 0.5 % of -- the switch between the
+# integer start and the f64 start pass (1.8 max(X) against 0.008 ||X||_F), and two more at 214 x 107 x 21
+R3_CASES = ["ialm_47x94x21_s301", "ialm_47x94x21_s305", "ialm_47x94x21_s302", "ialm_47x94x21_s303", "ialm_47x94x21_s304",
+            "ialm_107x214x21_s311", "ialm_107x214x21_s312"]
 
 
 def seeded_frames(g):
@@ -67,11 +71,13 @@ def seeded_frames(g):
     from oracle.scenes import scene, sha256
     n, H, W = (int(v) for v in g["shape"])
     frames = scene(np.random.default_rng(int(g["seed"])), n, H, W, blobs=int(g["blobs"]))
+    if "offset" in g.files:                      # round-3 fixtures: brightness offset (moves the side of the start switch)
+        frames = np.clip(frames.astype(np.int32) + int(g["offset"]), 0, 255).astype(np.uint8)
     assert sha256(frames) == str(g["frames_sha256"]), "scene generator no longer reproduces the fixture's input"
     return frames
 
 
-@pytest.mark.parametrize("name", SEEDED_CASES)
+@pytest.mark.parametrize("name", SEEDED_CASES + R3_CASES)
 def test_ialm_numpy_restatement_at_baseline_sizes(golden_dir, name):
     from oracle.scenes import sha256
     g = _load(golden_dir, name + ".npz")
@@ -85,6 +91,8 @@ def test_ialm_numpy_restatement_at_baseline_sizes(golden_dir, name):
     sparse = orc.rpca_epilogue(E).T.reshape(n, H, W)
     np.testing.assert_array_equal(sparse.reshape(n, -1).astype(np.int64).sum(axis=1), g["sparse_frame_sums"])
     assert sha256(sparse) == str(g["sparse_sha256"])
+    if "sparse" in g.files and g["sparse"].size:
+        np.testing.assert_array_equal(sparse, g["sparse"])
 
 
 @pytest.mark.parametrize("name", IALM_CASES)
