@@ -707,6 +707,8 @@ def dilate_up_u8(image, N):
 def roi_mask(frame, corners):
     """swk_roi_mask: (crop_region [(x0, y0), (x1, y1)], mask uint8 (Hc, Wc)) from the first BGR frame and the two
     chimney corners ((x1, y1), (x2, y2))."""
+    if hasattr(frame, "as_full_frame"):          # a ROI-stream frame (io_roi_stream.RoiFrame): the stored rectangle pasted into a blank frame
+        frame = frame.as_full_frame()
     if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3 or frame.strides[2] != 1 or frame.strides[1] != 3:
         frame = np.ascontiguousarray(frame, np.uint8)
     c = np.array([corners[0][0], corners[0][1], corners[1][0], corners[1][1]], np.int32)

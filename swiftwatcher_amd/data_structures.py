@@ -250,24 +250,23 @@ class FrameQueue(deque):
 
     # ---- the hot path, :171-217 ----
     def preprocess_queue(self, crop_region, resize_dim=None):
-        """:171-185.  "crop" is a view like in the reference; "grayscale" is produced on the GPU by
-        segment_queue's single library call and is resolved lazily if somebody reads it earlier."""
-        crops = [img.crop_frame(f, crop_region) for f in self.get_queue()]
-        self.store_processed_queue(crops, "crop")
-        for pos in range(len(self)):
-            crop = crops[pos]
-            self[pos].processed_frames["grayscale"] = (lambda c=crop: img.convert_grayscale(c))
+        """:171-185.  "crop" is the reference's view of the frame, made when it is first read; "grayscale" is produced on the
+        GPU by segment_queue's single library call and is resolved lazily if somebody reads it earlier."""
+        for slot in self:
+            frame = slot.frame
+            slot.processed_frames["crop"] = (lambda f=frame: img.crop_frame(f, crop_region))
+            slot.processed_frames["grayscale"] = (lambda f=frame: img.convert_grayscale(img.crop_frame(f, crop_region)))
 
     def _stage_window(self, min_seg_size, crop_region):
         """The window's ROI crops plus a margin of half the minimum segment size (clipped to the frame), stacked in
         page-locked memory: (staging array (n, Hm, Wm, 3), (x, y) of the ROI inside it, ROI (Hc, Wc))."""
         frames = self.get_queue()
-        (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(frames[0].shape, crop_region, min_seg_size)
-        shape = (len(frames), yb - ya, xb - xa) + frames[0].shape[2:]
-        if self._staging is None or self._staging.shape != shape:
-            self._staging = _lib.pinned_empty(shape, np.uint8, device=self.device)      # page-locked: the upload is one DMA
-        _lib.stage_frames(frames, ya, yb, xa, xb, self._staging)
-        return self._staging, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
+
+        def buffer(shape):
+            if self._staging is None or self._staging.shape != shape:
+                self._staging = _lib.pinned_empty(shape, np.uint8, device=self.device)  # page-locked: the upload is one DMA
+            return self._staging
+        return stack_frames(frames, crop_region, min_seg_size, buffer)
 
     def segment_queue(self, min_seg_size, crop_region):
         """:187-217: RPCA -> bilateral -> threshold -> opening -> CCL -> region properties ->
@@ -302,6 +301,29 @@ class FrameQueue(deque):
         window_segments(res["segs"], nseg, list(self), tuple(min_seg_size), crop_region, batch)
 
 
+def stack_frames(frames, crop_region, min_seg_size, buffer):
+    """frames (in the batch's frame order) -> (stack (F, Hm, Wm[, C]) uint8 in page-locked memory, (x, y) of the ROI inside a stacked
+    frame, ROI (Hc, Wc)).  Full decoded frames are cropped to the ROI plus its margin into buffer(shape) (swk_stage_frames).
+    RoiFrames of a ROI-stream reader (io_roi_stream.py) already ARE that rectangle: when they sit, in this order, in one of the
+    reader's page-locked blocks, the block itself is the stack -- no copy at all."""
+    first = frames[0]
+    (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(first.shape, crop_region, min_seg_size)
+    if hasattr(first, "roi"):
+        oy, ox = first.origin
+        h, w = first.roi.shape[:2]
+        if ya < oy or xa < ox or yb > oy + h or xb > ox + w:
+            raise ValueError("the ROI stream does not hold the crop region plus its margin")
+        block = first.block
+        if block is not None and block.shape[0] == len(frames) and all(f.block is block and f.slot == i for i, f in enumerate(frames)):
+            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0)
+        stack = buffer((len(frames), yb - ya, xb - xa) + first.shape[2:])
+        _lib.stage_frames([f.roi for f in frames], ya - oy, yb - oy, xa - ox, xb - ox, stack)
+        return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
+    stack = buffer((len(frames), yb - ya, xb - xa) + first.shape[2:])
+    _lib.stage_frames(frames, ya, yb, xa, xb, stack)
+    return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
+
+
 def _margin_rect(frame_shape, crop_region, min_seg_size):
     """(ya, yb, xa, xb) of the ROI plus half the minimum segment size, clipped to the frame, and the ROI (x0, y0, x1, y1) clipped."""
     Hf, Wf = frame_shape[:2]
@@ -321,17 +343,14 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     if not windows:
         return []
     n = len(windows[0][0])
-    first = windows[0][0][0]
-    (ya, yb, xa, xb), (x0, y0, x1, y1) = _margin_rect(first.shape, crop_region, min_seg_size)
     ctx = _lib.default_context(device)
-    stack = ctx.staging((len(windows) * n, yb - ya, xb - xa) + first.shape[2:])
     ordered = []
     for frames, _, _ in windows:
         if len(frames) != n:
             raise ValueError("every window needs the same number of frames")
         ordered.extend(frames[::-1])                         # queue index 0 = newest = last frame read (:134)
-    _lib.stage_frames(ordered, ya, yb, xa, xb, stack)
-    res = ctx.batch_run(stack, len(windows), n, crop=(x0 - xa, y0 - ya, x1 - x0, y1 - y0), params=params, stages=())
+    stack, (rx, ry), (Hc, Wc) = stack_frames(ordered, crop_region, min_seg_size, ctx.staging)
+    res = ctx.batch_run(stack, len(windows), n, crop=(rx, ry, Wc, Hc), params=params, stages=())
     nseg = res["nseg"]
     if np.any(nseg > res["segs"].shape[1]):
         raise _lib.SwkError("more regions in a frame than seg_cap")

@@ -1,0 +1,278 @@
+"""Pre-extracted ROI streams: the frame source that makes 10 k frames/s a 3 GB/s problem instead of a 62 GB/s one
+(SURVEY.md section 7 "Feeding 10k fps", section 8f rank 2).
+
+The counting loop only ever looks at the chimney's crop region of a frame -- plus, for segment images, at most half the minimum
+segment size beyond it (extract_segment_images grows small boxes, image_filtering.py:338-369).  A ROI stream file holds exactly
+that rectangle of every frame of a video (424 x 212 + 12 px margin = 317 KB instead of 6.2 MB per 1080p frame), written once by
+RoiStreamWriter from any source of decoded frames (the image has no video codec: decoding itself, io_video.py:85-165, stays out of
+scope).
+
+RoiStreamReader has the reference FrameReader's surface and bookkeeping (io_video.py:13-82): get_frame / get_n_frames / read_frame,
+frames past the end are all-zero "null" frames numbered -1 (:40-44), a failed read re-delivers the last good frame (:51-53) -- and
+because end_frame is the frame COUNT while the range test is inclusive, the frame one past the end is requested once and served by
+that rule, exactly like VideoReader / HDF5Reader.  What it hands out are RoiFrame objects: they index like the full frame
+(frame[y0:y1, x0:x1] in full-frame coordinates, which is all crop_frame and extract_segment_images do) but hold only the stored
+rectangle.
+
+get_n_frames(n) delivers a window as views of ONE page-locked block laid out in the queue's order (FrameQueue pushes with
+appendleft: the last frame read is queue position 0), so FrameQueue.segment_queue uploads that block as it is -- no staging copy --
+and a background thread fills the next window's block from the (memory-mapped) file while the current window is classified and
+tracked.  A block is reused two windows later; Frame objects still alive then (the tracker's cached frame, segments kept in
+events) get a private copy of their pixels first.
+"""
+import datetime
+import json
+import os
+import struct
+import threading
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+MAGIC = b"SWKROI1\n"
+
+
+def margin_rect(frame_hw, crop_region, min_seg_size=(24, 24)):
+    """(ya, yb, xa, xb): the crop region grown by half the minimum segment size, clipped to the frame -- every pixel
+    crop_frame and extract_segment_images can touch."""
+    Hf, Wf = frame_hw[:2]
+    (x0, y0), (x1, y1) = crop_region
+    x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, Wf), min(y1, Hf)
+    my, mx = int(min_seg_size[0]) // 2, int(min_seg_size[1]) // 2
+    return max(y0 - my, 0), min(y1 + my, Hf), max(x0 - mx, 0), min(x1 + mx, Wf)
+
+
+class RoiFrame:
+    """The stored rectangle of one frame, indexed in FULL-frame coordinates.  frame[ya:yb, xa:xb] (the two slices crop_frame and
+    extract_segment_images make) is translated and clipped like numpy clips a slice at the full frame's edges; anything else of
+    ndarray's interface is not offered -- the counting loop does not use it."""
+    __slots__ = ("roi", "origin", "shape", "dtype", "ndim", "block", "slot", "__weakref__")
+
+    def __init__(self, roi, origin, full_shape, block=None, slot=-1):
+        self.roi, self.origin, self.shape = roi, origin, tuple(full_shape)
+        self.dtype, self.ndim = roi.dtype, len(self.shape)
+        self.block, self.slot = block, slot
+
+    def __getitem__(self, key):
+        if not (isinstance(key, tuple) and len(key) >= 2 and isinstance(key[0], slice) and isinstance(key[1], slice)):
+            raise TypeError("a RoiFrame is indexed with two slices in full-frame coordinates: frame[y0:y1, x0:x1]")
+        oy, ox = self.origin
+        ys, ye, _ = key[0].indices(self.shape[0])
+        xs, xe, _ = key[1].indices(self.shape[1])
+        if key[0].step not in (None, 1) or key[1].step not in (None, 1):
+            raise TypeError("strided access to a RoiFrame")
+        h, w = self.roi.shape[:2]
+        if ys < oy or xs < ox or ye > oy + h or xe > ox + w:
+            if ye > ys and xe > xs:
+                raise IndexError("rows %d:%d, columns %d:%d leave the stored rectangle (rows %d:%d, columns %d:%d)"
+                                 % (ys, ye, xs, xe, oy, oy + h, ox, ox + w))
+        out = self.roi[max(ys - oy, 0):max(ye - oy, 0), max(xs - ox, 0):max(xe - ox, 0)]
+        if len(key) > 2:
+            out = out[(slice(None), slice(None)) + tuple(key[2:])]
+        # pixels that live in a reader's block are handed out as a copy: the block is reused two windows later
+        return out.copy() if self.block is not None else out
+
+    def detach(self):
+        """Private copy of the pixels: the block they live in is about to be reused."""
+        self.roi = self.roi.copy()
+        self.block, self.slot = None, -1
+
+    def as_full_frame(self, fill=128):
+        """A full-size ndarray with the stored rectangle pasted in (ROI-mask generation reads the first frame's crop region)."""
+        full = np.full(self.shape, fill, np.uint8)
+        oy, ox = self.origin
+        full[oy:oy + self.roi.shape[0], ox:ox + self.roi.shape[1]] = self.roi
+        return full
+
+
+class RoiStreamWriter:
+    """with RoiStreamWriter(path, frame_hw, crop_region, fps) as w: w.append(frame) ...   (frames: full decoded BGR frames)"""
+
+    def __init__(self, path, frame_hw, crop_region, fps=30.0, min_seg_size=(24, 24), channels=3):
+        self.rect = margin_rect(frame_hw, crop_region, min_seg_size)
+        ya, yb, xa, xb = self.rect
+        self.meta = dict(version=1, fps=float(fps), frame_hw=[int(frame_hw[0]), int(frame_hw[1])], channels=int(channels),
+                         crop_region=[[int(crop_region[0][0]), int(crop_region[0][1])], [int(crop_region[1][0]), int(crop_region[1][1])]],
+                         min_seg_size=[int(min_seg_size[0]), int(min_seg_size[1])], rect=[ya, yb, xa, xb], frames=0)
+        self._fh = open(path, "wb")
+        self._fh.write(MAGIC + struct.pack("<I", 4096))
+        self._fh.write(b"\0" * (4096 - len(MAGIC) - 4))              # the JSON header is written on close (frame count)
+        self.path = path
+
+    def append(self, frame):
+        ya, yb, xa, xb = self.rect
+        if tuple(frame.shape[:2]) != tuple(self.meta["frame_hw"]) or frame.dtype != np.uint8:
+            raise ValueError("frame shape / dtype differs from the stream's")
+        self._fh.write(np.ascontiguousarray(frame[ya:yb, xa:xb]).tobytes())
+        self.meta["frames"] += 1
+
+    def close(self):
+        if self._fh is None:
+            return
+        blob = json.dumps(self.meta).encode()
+        if len(blob) > 4096 - len(MAGIC) - 4 - 1:
+            raise ValueError("header too large")
+        self._fh.seek(len(MAGIC) + 4)
+        self._fh.write(blob)
+        self._fh.close()
+        self._fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def write_roi_stream(path, frames, crop_region, fps=30.0, min_seg_size=(24, 24)):
+    first = frames[0]
+    with RoiStreamWriter(path, first.shape[:2], crop_region, fps, min_seg_size, channels=1 if first.ndim == 2 else first.shape[2]) as w:
+        for f in frames:
+            w.append(f)
+    return path
+
+
+class RoiStreamReader:
+    """FrameReader over a ROI stream file (io_video.py:13-82 bookkeeping).  prefetch=True reads the next window ahead in a thread."""
+
+    BLOCKS = 3
+
+    def __init__(self, path, start=0, end=0, prefetch=True, device=0):
+        self.filepath = path
+        with open(path, "rb") as fh:
+            head = fh.read(len(MAGIC) + 4)
+            if head[:len(MAGIC)] != MAGIC:
+                raise ValueError("%s is not a ROI stream" % path)
+            hdr = struct.unpack("<I", head[len(MAGIC):])[0]
+            self.meta = json.loads(fh.read(hdr - len(MAGIC) - 4).split(b"\0", 1)[0].decode())
+        m = self.meta
+        ya, yb, xa, xb = m["rect"]
+        self.rect, self.origin = (ya, yb, xa, xb), (ya, xa)
+        self.crop_region = [tuple(m["crop_region"][0]), tuple(m["crop_region"][1])]
+        self.min_seg_size = tuple(m["min_seg_size"])
+        ch = m["channels"]
+        self.roi_shape = (yb - ya, xb - xa) + ((ch,) if ch > 1 else ())
+        self.full_shape = (m["frame_hw"][0], m["frame_hw"][1]) + ((ch,) if ch > 1 else ())
+        self.count = int(m["frames"])
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r", offset=hdr, shape=(self.count,) + self.roi_shape)
+        self.fps = m["fps"]
+        self.start_frame = start
+        self.end_frame = end if end > 0 else self.count
+        self.next_frame_number = self.start_frame
+        self.total_frames = self.end_frame - self.start_frame
+        self.frame_shape = self.full_shape
+        self.last_read_frame = None
+        self.frames_read = 0
+        self.read_errors = 0
+        self.device = device
+        self._midnight = datetime.datetime.combine(datetime.date.today(), datetime.time())
+        self._blocks, self._alive, self._turn = [], [], 0
+        self._prefetch = prefetch
+        self._pending = None                 # (first frame number, n, block index, thread)
+
+    # ---- the reference reader's surface ----
+    def frame_number_to_timestamp(self, frame_number):
+        from .io_data import frame_timestamp_ns
+        return self._midnight + datetime.timedelta(microseconds=frame_timestamp_ns(frame_number, self.fps) // 1000)
+
+    def read_frame(self, frame_number, increment=True):
+        """One frame as a RoiFrame with private pixels (None past the end of the file, like a failed cv2 read)."""
+        frame = None
+        if 0 <= frame_number < self.count:
+            frame = RoiFrame(np.array(self._mm[frame_number]), self.origin, self.full_shape)
+        if increment:
+            self.next_frame_number += 1
+        return frame
+
+    def get_frame(self, frame_number=None):
+        if frame_number is None:
+            frame_number = self.next_frame_number
+        if not self.start_frame <= frame_number <= self.end_frame:
+            return RoiFrame(np.zeros(self.roi_shape, np.uint8), self.origin, self.full_shape), -1, "00:00:00.000"
+        frame = self.read_frame(frame_number)
+        timestamp = self.frame_number_to_timestamp(frame_number)
+        if frame is None:
+            frame = self.last_read_frame
+            self.read_errors += 1
+        else:
+            self.last_read_frame = frame
+            self.frames_read += 1
+        return frame, frame_number, timestamp
+
+    # ---- a window at a time: one page-locked block in queue order, next window read ahead ----
+    def _block(self, n):
+        if not self._blocks or self._blocks[0].shape[0] != n:
+            self._blocks = [_lib.pinned_empty((n,) + self.roi_shape, np.uint8, device=self.device) for _ in range(self.BLOCKS)]
+            self._alive = [[] for _ in range(self.BLOCKS)]
+        b = self._turn
+        self._turn = (b + 1) % self.BLOCKS
+        for ref in self._alive[b]:                       # frames of the window this block held, still referenced somewhere
+            fr = ref()
+            if fr is not None and fr.block is self._blocks[b]:
+                fr.detach()
+        self._alive[b] = []
+        return b
+
+    def _fill(self, b, first, n):
+        """Pixels of frames first .. first + n - 1 into block b, frame k at slot n - 1 - k (the queue's order); nulls are zeros,
+        the frame one past the end repeats the last one (get_frame's fallback)."""
+        block = self._blocks[b]
+        real = [k for k in range(n) if self.start_frame <= first + k <= self.end_frame and first + k < self.count]
+        if real:
+            k0, k1 = real[0], real[-1]
+            src = [self._mm[first + k] for k in range(k1, k0 - 1, -1)]                  # newest first = ascending slots
+            _lib.stage_frames(src, 0, self.roi_shape[0], 0, self.roi_shape[1], block[n - 1 - k1:n - k0])
+        for k in range(n):
+            number = first + k
+            if not self.start_frame <= number <= self.end_frame:
+                block[n - 1 - k] = 0
+            elif number >= self.count:
+                if k > 0 and number - 1 < self.count:
+                    block[n - 1 - k] = block[n - k]
+                elif self.last_read_frame is not None:
+                    block[n - 1 - k] = self.last_read_frame.roi
+                else:
+                    block[n - 1 - k] = 0
+
+    def _start_prefetch(self, first, n):
+        if not self._prefetch or first > self.end_frame:
+            self._pending = None
+            return
+        b = self._block(n)
+        th = threading.Thread(target=self._fill, args=(b, first, n), daemon=True)
+        th.start()
+        self._pending = (first, n, b, th)
+
+    def get_n_frames(self, n):
+        first = self.next_frame_number
+        pend = self._pending
+        if pend is not None and pend[0] == first and pend[1] == n:
+            pend[3].join()
+            b = pend[2]
+        else:
+            if pend is not None:
+                pend[3].join()
+            b = self._block(n)
+            self._fill(b, first, n)
+        self._pending = None
+        block = self._blocks[b]
+        frames, numbers, stamps = [], [], []
+        for k in range(n):
+            number = self.next_frame_number
+            if not self.start_frame <= number <= self.end_frame:
+                fr, num, ts = RoiFrame(block[n - 1 - k], self.origin, self.full_shape, block, n - 1 - k), -1, "00:00:00.000"
+            else:
+                fr = RoiFrame(block[n - 1 - k], self.origin, self.full_shape, block, n - 1 - k)
+                num, ts = number, self.frame_number_to_timestamp(number)
+                self.next_frame_number += 1
+                if number < self.count:
+                    self.last_read_frame = fr
+                    self.frames_read += 1
+                else:
+                    self.read_errors += 1
+            self._alive[b].append(weakref.ref(fr))
+            frames.append(fr); numbers.append(num); stamps.append(ts)
+        self._start_prefetch(self.next_frame_number, n)
+        return frames, numbers, stamps

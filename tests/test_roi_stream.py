@@ -1,0 +1,135 @@
+"""ROI-stream ingest (swiftwatcher_amd/io_roi_stream.py): writer + FrameReader-compatible reader over the
+pre-cropped ROI (+ margin) of every frame.  CPU: the reader's bookkeeping equals ArrayReader's (which restates io_video.py:13-82) on
+the same clip -- frame numbers, timestamps, null frames past the end, the re-delivered last frame -- and RoiFrame indexing equals
+full-frame slicing wherever the counting loop slices.  GPU: the counting loop over a ROI stream equals the run over full frames."""
+import numpy as np
+import pytest
+
+from swiftwatcher_amd.io_frames import ArrayReader
+from swiftwatcher_amd.io_roi_stream import RoiStreamReader, RoiFrame, write_roi_stream, margin_rect
+
+
+def _clip(total, hw=(120, 200), seed=0):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, size=hw + (3,), dtype=np.uint8) for _ in range(total)]
+
+
+CROP = [(40, 30), (160, 90)]
+
+
+@pytest.mark.parametrize("total,n,prefetch", [(52, 21, True), (52, 21, False), (63, 21, True), (10, 21, True), (44, 7, True)])
+def test_reader_bookkeeping_equals_array_reader(tmp_path, total, n, prefetch):
+    clip = _clip(total)
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), clip, CROP, fps=29.97)
+    a, b = ArrayReader(clip, fps=29.97), RoiStreamReader(path, prefetch=prefetch)
+    assert (b.total_frames, b.fps, b.start_frame, b.end_frame, b.frame_shape) == (a.total_frames, a.fps, a.start_frame, a.end_frame, (120, 200, 3))
+    ya, yb, xa, xb = margin_rect((120, 200), CROP)
+    assert (ya, yb, xa, xb) == (18, 102, 28, 172)
+    for _ in range(total // n + 2):
+        fa, na, ta = a.get_n_frames(n)
+        fb, nb, tb = b.get_n_frames(n)
+        assert na == nb and ta == tb
+        assert (a.next_frame_number, a.frames_read, a.read_errors) == (b.next_frame_number, b.frames_read, b.read_errors)
+        for x, y in zip(fa, fb):
+            assert isinstance(y, RoiFrame) and y.shape == x.shape
+            np.testing.assert_array_equal(y[30:90, 40:160], x[30:90, 40:160])               # crop_frame
+            np.testing.assert_array_equal(y[18:42, 150:172], x[18:42, 150:172])             # a segment box grown into the margin
+            np.testing.assert_array_equal(y.roi, x[ya:yb, xa:xb])
+        # the window sits in ONE block in the queue's order (appendleft: last frame read = position 0)
+        assert all(f.block is fb[0].block and f.slot == n - 1 - k for k, f in enumerate(fb))
+    # single-frame interface
+    c = RoiStreamReader(path, prefetch=False)
+    f0 = c.read_frame(0, increment=False)
+    np.testing.assert_array_equal(f0.as_full_frame()[30:90, 40:160], clip[0][30:90, 40:160])
+    fr, num, ts = c.get_frame()
+    assert num == 0 and ts == a.frame_number_to_timestamp(0)
+    assert c.get_frame(total + 5)[1] == -1 and not c.get_frame(total + 5)[0].roi.any()
+    with pytest.raises(IndexError):
+        f0[0:10, 0:10]
+    with pytest.raises(TypeError):
+        f0[3]
+
+
+def test_blocks_are_recycled_only_after_live_frames_got_their_own_pixels(tmp_path):
+    clip = _clip(21 * 6, seed=3)
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), clip, CROP)
+    r = RoiStreamReader(path)
+    ya, yb, xa, xb = margin_rect((120, 200), CROP)
+    held = []
+    for w in range(6):
+        frames, numbers, _ = r.get_n_frames(21)
+        held.append((frames[3], numbers[3], frames[3][30:60, 40:80]))
+        for fr, num, cut in held:                         # frames (and cuts) of every earlier window still show their own pixels
+            np.testing.assert_array_equal(fr.roi, clip[num][ya:yb, xa:xb])
+            np.testing.assert_array_equal(cut, clip[num][30:60, 40:80])
+    assert held[0][0].block is None and held[5][0].block is not None
+
+
+def test_queue_uploads_the_readers_block_without_a_copy(tmp_path):
+    """stack_frames: RoiFrames that sit in one block in queue order -> the block itself; anything else is staged."""
+    from swiftwatcher_amd.data_structures import FrameQueue, stack_frames
+    clip = _clip(42, seed=5)
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), clip, CROP)
+    r = RoiStreamReader(path)
+    q = FrameQueue()
+    frames, numbers, stamps = r.get_n_frames(21)
+    q.push_list_of_frames(frames, numbers, stamps)
+    made = []
+    stack, (rx, ry), (Hc, Wc) = stack_frames(q.get_queue(), CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert stack is frames[0].block and not made and (rx, ry, Hc, Wc) == (12, 12, 60, 120)
+    for pos in range(21):
+        np.testing.assert_array_equal(stack[pos][ry:ry + Hc, rx:rx + Wc], clip[20 - pos][30:90, 40:160])
+    # a shuffled queue (or frames of two windows) is staged instead
+    mixed = q.get_queue()[::-1]
+    stack2, (rx2, ry2), _ = stack_frames(mixed, CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert made == [(21, 84, 144, 3)] and (rx2, ry2) == (12, 12)
+    for pos in range(21):
+        np.testing.assert_array_equal(stack2[pos][ry2:ry2 + Hc, rx2:rx2 + Wc], clip[pos][30:90, 40:160])
+    # full frames: cropped to ROI + margin
+    stack3, (rx3, ry3), _ = stack_frames([clip[i] for i in range(20, -1, -1)], CROP, (24, 24), lambda shape: np.empty(shape, np.uint8))
+    np.testing.assert_array_equal(stack3, stack)
+
+
+@pytest.mark.gpu
+def test_counting_loop_over_a_roi_stream_equals_the_full_frame_run(tmp_path):
+    """swift_counting_algorithm reading a ROI stream (zero-copy upload of the reader's blocks, read-ahead thread) gives the events of
+    the run over the full decoded frames: same segments, crops (the classifier reads the margin), tracker, count -- with the crop
+    region handed in and derived from the corners (generate_regions on the stream's first frame)."""
+    import torch
+    from swiftwatcher_amd import synthetic, pipeline
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref
+    from helpers import event_signature
+    corners = [(250, 200), (420, 201)]
+    crop_region = img.generate_crop_region(corners)
+    (x0, y0), (x1, y1) = crop_region
+    total = 75
+    clip = synthetic.full_frames(91, total, crop_region, frame_hw=(360, 640), birds=8, bird_len=(10, 16), bird_wid=(5, 8))[::-1].copy()
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), list(clip), crop_region)
+    assert (tmp_path / "clip.swkroi").stat().st_size < 0.25 * clip.nbytes
+    roi_mask = np.zeros((y1 - y0, x1 - x0), np.uint8)
+    roi_mask[(y1 - y0) // 2:, 20:-20] = 255
+    # a classifier that keeps some: random weights, head calibrated on the first window's crops
+    from swiftwatcher_amd.data_structures import FrameQueue
+    q = FrameQueue()
+    q.push_list_of_frames(list(clip[:21]), list(range(21)), ["t"] * 21)
+    q.preprocess_queue(crop_region, None)
+    q.segment_queue((24, 24), crop_region)
+    crops = [s.segment_image for f in q for s in f.segments]
+    assert len(crops) > 40
+    sd = classifier_ref.calibrate_head(classifier_ref.random_state_dict(8), crops)
+    clf = SegmentClassifier.from_state_dict(sd)
+    for kw in (dict(), dict(classifier=clf), dict(classifier=clf, windows_per_call=2)):
+        count_a, events_a = pipeline.count_swifts(list(clip), crop_region, roi_mask, **kw)
+        events_b = pipeline.swift_counting_algorithm(RoiStreamReader(path), crop_region, roi_mask, **kw)
+        assert event_signature(events_b) == event_signature(events_a), kw
+        assert ec.count_swifts(events_b) == count_a
+        for ea, eb in zip(events_a, events_b):
+            for sa, sb in zip(ea, eb):
+                np.testing.assert_array_equal(sa.segment_image, sb.segment_image)
+    assert len(events_a) >= 1
+    events_c = pipeline.swift_counting_algorithm(RoiStreamReader(path), corners=corners)
+    count_d, events_d = pipeline.count_swifts(list(clip), corners=corners)
+    assert event_signature(events_c) == event_signature(events_d)
