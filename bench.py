@@ -231,46 +231,47 @@ def reference_call_pattern(ctx_device, clf, args, geo):
                       "segments_per_window": nseg, "ialm_iters": q.last_iters}
     del frames, order, q
     # ---- count_loop: swift_counting_algorithm (__main__.py:56-100), classifier ON (the bench's calibrated head), tracker, events ----
-    total = n * args.loop_windows
-    clip = synthetic.full_frames(5, total, crop_region, birds=12)[::-1]          # oldest first
-    flist = [clip[i] for i in range(total)]
+    # The clip (loop_windows x 21 frames of 1080p, 130 MB per window in host memory) is played `cycles` times in a row for the timed
+    # run: a video is hours long, and the first windows of a process pay for memory the loop then recycles (fresh pages are
+    # expensive in this sandbox: one batch of Segment objects that had to grow the heap took 20 x longer than the others).
+    import gc
+    import tempfile
+    from swiftwatcher_amd.io_roi_stream import RoiStreamReader, write_roi_stream
+    cycles = 3
+    clip = synthetic.full_frames(5, n * args.loop_windows, crop_region, birds=12)[::-1]          # oldest first
+    flist = [clip[i] for i in range(n * args.loop_windows)]
+    total = len(flist) * cycles
     roi_mask = np.zeros((212, 424), np.uint8)
     roi_mask[100:, 42:382] = 255
     loop = {}
-    for name, kw in (("reference_pattern", dict()), ("windows_per_call_8", dict(windows_per_call=8))):
-        for timed in (False, True):                                      # first run = warm-up (staging buffers, tile pools, graphs)
-            reader = ArrayReader(flist)
-            t0 = time.perf_counter()
-            events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=clf, keep_stages=True, **kw)
-            dt = time.perf_counter() - t0
-        loop[name] = {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_window": round(dt / args.loop_windows * 1e3, 3),
-                      "events": len(events), "count": int(ec.count_swifts(events))}
-    reader = ArrayReader(flist)
-    t0 = time.perf_counter()
-    events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=None, keep_stages=True)
-    dt = time.perf_counter() - t0
-    loop["reference_pattern_no_classify"] = {"value": round(total / dt, 1), "unit": "frames/s", "events": len(events),
-                                             "count": int(ec.count_swifts(events))}
+
+    def run_loop(make_reader, classifier, **kw):
+        events = pipeline.swift_counting_algorithm(make_reader(1), crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
+        del events
+        gc.collect()
+        t0 = time.perf_counter()
+        events = pipeline.swift_counting_algorithm(make_reader(cycles), crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
+        dt = time.perf_counter() - t0
+        return {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_window": round(dt / (args.loop_windows * cycles) * 1e3, 3),
+                "frames": total, "events": len(events), "count": int(ec.count_swifts(events))}
+
+    arrays = lambda c: ArrayReader(flist * c)                            # noqa: E731
+    loop["reference_pattern"] = run_loop(arrays, clf)
+    loop["windows_per_call_8"] = run_loop(arrays, clf, windows_per_call=8)
+    loop["reference_pattern_no_classify"] = run_loop(arrays, None)
     # the same loop fed by a ROI stream file (io_roi_stream.py: the crop region + margin of every frame, 317 KB instead of 6.2 MB;
     # the reader's page-locked blocks are uploaded as they are, the next window is read ahead in a thread)
-    import tempfile
-    from swiftwatcher_amd.io_roi_stream import RoiStreamReader, write_roi_stream
     with tempfile.TemporaryDirectory() as tmp:
-        path = write_roi_stream(os.path.join(tmp, "clip.swkroi"), flist, crop_region)
-        for name, kw in (("roi_stream", dict()), ("roi_stream_windows_per_call_8", dict(windows_per_call=8))):
-            for timed in (False, True):
-                reader = RoiStreamReader(path, device=ctx_device)
-                t0 = time.perf_counter()
-                events = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=clf, keep_stages=True, **kw)
-                dt = time.perf_counter() - t0
-            loop[name] = {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_window": round(dt / args.loop_windows * 1e3, 3),
-                          "events": len(events), "count": int(ec.count_swifts(events)),
-                          "input_mb_per_frame": round(os.path.getsize(path) / total / 1e6, 3)}
+        paths = {c: write_roi_stream(os.path.join(tmp, "clip%d.swkroi" % c), flist * c, crop_region) for c in (1, cycles)}
+        stream = lambda c: RoiStreamReader(paths[c], device=ctx_device)  # noqa: E731
+        loop["roi_stream"] = run_loop(stream, clf)
+        loop["roi_stream_windows_per_call_8"] = run_loop(stream, clf, windows_per_call=8)
+        loop["roi_stream"]["input_mb_per_frame"] = round(os.path.getsize(paths[1]) / len(flist) / 1e6, 3)
     out["count_loop"] = dict(loop["reference_pattern"], roi_stream=loop["roi_stream"],
                              roi_stream_windows_per_call_8=loop["roi_stream_windows_per_call_8"],
                              what="swift_counting_algorithm as __main__.py:56-100 runs it: get_n_frames -> FrameQueue() -> classifier(frame.segments) "
-                                  "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory, --classify on (the "
-                                  "bench's calibrated head)" % total,
+                                  "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory played %d times, "
+                                  "--classify on (the bench's calibrated head)" % (len(flist), cycles),
                              windows_per_call_8=loop["windows_per_call_8"], no_classify=loop["reference_pattern_no_classify"])
     return out
 

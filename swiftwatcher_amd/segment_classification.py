@@ -242,12 +242,15 @@ class CroppedSqueezeNet10:
         return self._buf
 
     @torch.no_grad()
-    def __call__(self, tiles):
-        """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input."""
+    def __call__(self, tiles, row0=0):
+        """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input.  row0: first row of the persistent
+        per-layer tiles this forward works in (two forwards on disjoint row ranges may run side by side on two streams)."""
         if tiles.is_cuda and self.memory_format == torch.channels_last and all(
                 kind != "fire" or not (pad[0] or pad[1]) for kind, _, _, _, _, pad, _ in self.plan):
             with torch.cuda.device(tiles.device):            # the glue kernels go to this device's current stream
-                return self._forward_hip_glue(tiles)
+                return self._forward_hip_glue(tiles, row0)
+        if row0:
+            raise ValueError("row0 is a feature of the GPU path")
         m = self.model
         conv2d = torch.nn.functional.conv2d
         k = tiles.shape[0]
@@ -279,7 +282,7 @@ class CroppedSqueezeNet10:
         s = torch.relu(m.classifier[1](x)).sum(dim=(2, 3))
         return (s + self.ring_sum) / self.n_pos
 
-    def _forward_hip_glue(self, tiles):
+    def _forward_hip_glue(self, tiles, row0=0):
         """The same forward on the GPU with the convolutions alone left to MIOpen: bias + ReLU + placement into the
         next tile is one HIP kernel per convolution output (swk_nhwc_bias_relu_place), max-pooling another
         (swk_nhwc_maxpool3s2), both on PyTorch's current stream.  Same float32 operations per element as above."""
@@ -289,7 +292,8 @@ class CroppedSqueezeNet10:
         m = self.model
         conv2d = torch.nn.functional.conv2d
         k = tiles.shape[0]
-        bufs, live = self._buffers(k)
+        bufs, live = self._buffers(row0 + k)
+        rows = slice(row0, row0 + k)
         cl = torch.channels_last
 
         def nhwc(t):
@@ -344,10 +348,10 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_maxpool3s2 failed (%d)" % rc)
 
-        aux = self._aux_buffers(k)
+        aux = self._aux_buffers(row0 + k)
         conv1 = m.features[0]
         a, b = self.pool1_slice
-        c1buf = aux["conv1"][:k]
+        c1buf = aux["conv1"][rows]
         side = tiles.shape[2]
         if self.fused_conv1 and conv1.out_channels == 96 and side % 2 == 0 and 2 * (b - 1) + 8 <= side:
             # conv1 + bias + ReLU on the rows the first pool reads, one kernel (csrc/cnn_conv1.hip)
@@ -361,22 +365,22 @@ class CroppedSqueezeNet10:
         else:
             e = conv2d(nhwc(tiles), conv1.weight, None, stride=conv1.stride)
             place(e, conv1.bias, c1buf, a, b - a, 0, 0)
-        x = aux["pool_in"][:k]
+        x = aux["pool_in"][rows]
         pool(c1buf, x)
         pi = 0
         for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
             if kind == "pool":
-                x = aux["pool_out"][pi][:k]
-                pool(bufs[j][:k], x)
+                x = aux["pool_out"][pi][rows]
+                pool(bufs[j][rows], x)
                 pi += 1
                 continue
-            sq = bufs[j][:k]
+            sq = bufs[j][rows]
             c, cn = crop
             c1 = layer.expand1x1.out_channels
             if live[j] is not None:
-                dest, doff = live[j][:k], 0
+                dest, doff = live[j][rows], 0
             else:
-                dest, doff = bufs[j + 1][:k], self.plan[j + 1][3]
+                dest, doff = bufs[j + 1][rows], self.plan[j + 1][3]
             if self.fused_1x1:
                 # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
                 # (csrc/cnn_conv1x1.hip)
@@ -485,6 +489,7 @@ class SegmentClassifier:
         self._graphs = {}
         self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
         self._graph_error = None
+        self._two_branches = os.environ.get("SWK_GRAPH_BRANCHES", "2") == "2"
 
     def preprocess(self, segment_images, window=False):
         """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device, or with
@@ -540,8 +545,22 @@ class SegmentClassifier:
                 self._forward(x)                                            # kernel attributes, persistent tiles, library handles
                 torch.cuda.current_stream(self.device).synchronize()
                 graph = torch.cuda.CUDAGraph()
+                rows = int(x.shape[0])
+                half = (rows // 2 + 31) // 32 * 32
                 with torch.cuda.graph(graph):
-                    out = self._forward(x)
+                    if self._two_branches and self.cropped is not None and rows >= 128:
+                        # two independent halves on two streams inside the graph: at a window's size a kernel does not fill
+                        # the chip for long, and the halves' launches, ramps and tails overlap
+                        main = torch.cuda.current_stream(self.device)
+                        side = torch.cuda.Stream(self.device)
+                        side.wait_stream(main)
+                        lo = self.cropped(x[:half], 0)
+                        with torch.cuda.stream(side):
+                            hi = self.cropped(x[half:], half)
+                        main.wait_stream(side)
+                        out = torch.cat([lo, hi])
+                    else:
+                        out = self._forward(x)
                 if len(self._graphs) >= 24:
                     self._graphs.clear()
                 entry = self._graphs[key] = (graph, out)

@@ -639,3 +639,23 @@ def test_window_score_table_equals_per_frame_calls(tmp_path):
     some = [s for f in q for s in f.segments][:3]
     cp = copy.deepcopy(some)
     assert all(not hasattr(c, "_batch") for c in cp) and all(np.array_equal(c.segment_image, s.segment_image) for c, s in zip(cp, some))
+
+
+@pytest.mark.gpu
+def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
+    """A FrameQueue window's forward (<= 512 rows on a persistent input slot) is captured once as a HIP graph -- from 128 rows on as
+    two halves on two streams inside the graph -- and replayed: bit-identical to launching the kernels one by one."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    clf = SegmentClassifier.from_state_dict(ref.random_state_dict(12), batch_size=1024)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for rows in (64, 192, 320, 512):
+        x = torch.randn((rows, 3, 40, 40), generator=g).to(clf.device).contiguous(memory_format=torch.channels_last)
+        eager = clf._forward(x).clone()
+        first = clf._forward_graphed(x).clone()              # captures
+        again = clf._forward_graphed(x).clone()              # replays
+        assert clf._use_graphs and clf._graph_error is None, clf._graph_error
+        assert torch.equal(first, eager) and torch.equal(again, eager), rows
+        x.add_(0.25)                                          # same buffer, new contents: the replay reads them
+        assert torch.equal(clf._forward_graphed(x), clf._forward(x))
+    assert len(clf._graphs) == 4
