@@ -489,7 +489,6 @@ class SegmentClassifier:
         self._graphs = {}
         self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
         self._graph_error = None
-        self._two_branches = os.environ.get("SWK_GRAPH_BRANCHES", "2") == "2"
 
     def preprocess(self, segment_images, window=False):
         """(:18-24, :31-33) for a list of HxWx3 uint8 crops -> float32 (B, 3, 224, 224) on the device, or with
@@ -545,22 +544,10 @@ class SegmentClassifier:
                 self._forward(x)                                            # kernel attributes, persistent tiles, library handles
                 torch.cuda.current_stream(self.device).synchronize()
                 graph = torch.cuda.CUDAGraph()
-                rows = int(x.shape[0])
-                half = (rows // 2 + 31) // 32 * 32
                 with torch.cuda.graph(graph):
-                    if self._two_branches and self.cropped is not None and rows >= 128:
-                        # two independent halves on two streams inside the graph: at a window's size a kernel does not fill
-                        # the chip for long, and the halves' launches, ramps and tails overlap
-                        main = torch.cuda.current_stream(self.device)
-                        side = torch.cuda.Stream(self.device)
-                        side.wait_stream(main)
-                        lo = self.cropped(x[:half], 0)
-                        with torch.cuda.stream(side):
-                            hi = self.cropped(x[half:], half)
-                        main.wait_stream(side)
-                        out = torch.cat([lo, hi])
-                    else:
-                        out = self._forward(x)
+                    # (two halves on two streams inside the graph -- forwards on disjoint rows of the persistent tiles, row0 --
+                    # were measured: 3.11 against 3.17 ms per window of the counting loop, no gain; one chain it is)
+                    out = self._forward(x)
                 if len(self._graphs) >= 24:
                     self._graphs.clear()
                 entry = self._graphs[key] = (graph, out)

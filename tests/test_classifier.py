@@ -643,8 +643,9 @@ def test_window_score_table_equals_per_frame_calls(tmp_path):
 
 @pytest.mark.gpu
 def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
-    """A FrameQueue window's forward (<= 512 rows on a persistent input slot) is captured once as a HIP graph -- from 128 rows on as
-    two halves on two streams inside the graph -- and replayed: bit-identical to launching the kernels one by one."""
+    """A FrameQueue window's forward (<= 512 rows on a persistent input slot) is captured once as a HIP graph and replayed:
+    bit-identical to launching the kernels one by one.  Forwards on disjoint row ranges of the persistent per-layer tiles (row0)
+    give each row the result it has in a forward of its own."""
     from swiftwatcher_amd.segment_classification import SegmentClassifier
     from oracle import classifier_ref as ref
     clf = SegmentClassifier.from_state_dict(ref.random_state_dict(12), batch_size=1024)
@@ -659,3 +660,6 @@ def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
         x.add_(0.25)                                          # same buffer, new contents: the replay reads them
         assert torch.equal(clf._forward_graphed(x), clf._forward(x))
     assert len(clf._graphs) == 4
+    x = torch.randn((96, 3, 40, 40), generator=g).to(clf.device).contiguous(memory_format=torch.channels_last)
+    whole = clf.cropped(x)
+    np.testing.assert_allclose(torch.cat([clf.cropped(x[:32], 0), clf.cropped(x[32:], 32)]).cpu().numpy(), whole.cpu().numpy(), atol=1e-6, rtol=1e-6)
