@@ -143,8 +143,9 @@ void launch_ccl(hipStream_t s, const uint8_t *src, int F, int H, int W, int conn
 {
     if (connectivity == 4) order = SWK_ORDER_RASTER;       // OpenCV's 4-way algorithm numbers in raster order
     const int conn8 = connectivity == 8;
-    (void)hipMemsetAsync(b.parent, 0xFF, (size_t)F * b.Pp * sizeof(int32_t), s);
-    (void)hipMemsetAsync(b.rootbits, 0, (size_t)F * b.words * sizeof(uint32_t), s);
+    hipError_t me = hipMemsetAsync(b.parent, 0xFF, (size_t)F * b.Pp * sizeof(int32_t), s);
+    if (me == hipSuccess) me = hipMemsetAsync(b.rootbits, 0, (size_t)F * b.words * sizeof(uint32_t), s);
+    if (me != hipSuccess) { g_launch_error = (int)me; return; }          // surfaces at the context's next sync()
     for (int f0 = 0; f0 < F; f0 += 32768) {
         const int fc = F - f0 < 32768 ? F - f0 : 32768;
         const dim3 grid((W + 255) / 256, H, fc), blk(256);

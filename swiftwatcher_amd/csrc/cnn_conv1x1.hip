@@ -155,7 +155,10 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + SLOTS - 1) / SLOTS;
     // persistent over the row tiles: one 16-wave workgroup per CU, or one / two 8-wave ones
-    const int64_t cap = NWV == 16 ? 256 : lds > 80 * 1024 ? 256 : 512;
+    // (as many workgroups per CU as their waves and their LDS allow)
+    const int64_t by_lds = (int64_t)((160 * 1024 - 256) / lds), by_waves = 16 / NWV;
+    const int64_t per_cu = by_lds < 1 ? 1 : (by_lds < by_waves ? by_lds : by_waves);
+    const int64_t cap = 256 * per_cu;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>), dim3((unsigned)blocks), dim3(64 * NWV), lds, s, src, rows, sh, sw, cin, crop_y,
                        crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off, FastDiv((unsigned)(h * w)), FastDiv((unsigned)w));
@@ -172,9 +175,22 @@ static int launch_conv1x1(hipStream_t s, const float *src, int64_t rows, int sh,
 {
     constexpr int CS = NBLK >= 6 ? 2 : 1;          // 64 accumulator registers per wave at most
     if (g_conv1x1_ring == 0) {
-        if (cin % 32 == 0) return launch_conv1x1_d<NBLK, 32, 1, CS, 16>(SWK_C1_ARGS);          // whole 128-byte lines per pixel and chunk
-        if (cin == 48) return launch_conv1x1_d<NBLK, 48, 1, CS, 16>(SWK_C1_ARGS);              // one pixel = one chunk (192 bytes)
-        return launch_conv1x1_d<NBLK, 16, 1, CS, 16>(SWK_C1_ARGS);
+        // A workgroup takes NWV / CS row tiles (32 pixels each) per round and there is one workgroup per CU (the weight matrix fills
+        // the LDS): a FrameQueue window's worth of segments (a few hundred rows of the batch, 10-40 k pixels) would keep 20-80 of the 256
+        // CUs busy with 16-wave workgroups (82 us for 512 -> 64 on 9 x 9 at batch 256, 14 us per 256 rows at batch 4096).  Fewer waves
+        // per workgroup spread the same tiles over more CUs.
+        const int64_t ntiles = (rows + 31) / 32;
+        const int nwv = ntiles >= 16 * 160 / CS ? 16 : ntiles >= 8 * 160 / CS ? 8 : 4;
+#define SWK_C1_BY_WAVES(KC)                                                              \
+        do {                                                                             \
+            if (nwv == 16) return launch_conv1x1_d<NBLK, KC, 1, CS, 16>(SWK_C1_ARGS);    \
+            if (nwv == 8) return launch_conv1x1_d<NBLK, KC, 1, CS, 8>(SWK_C1_ARGS);      \
+            return launch_conv1x1_d<NBLK, KC, 1, CS, 4>(SWK_C1_ARGS);                    \
+        } while (0)
+        if (cin % 32 == 0) SWK_C1_BY_WAVES(32);          // whole 128-byte lines per pixel and chunk
+        if (cin == 48) SWK_C1_BY_WAVES(48);              // one pixel = one chunk (192 bytes)
+        SWK_C1_BY_WAVES(16);
+#undef SWK_C1_BY_WAVES
     }
     if (cin % 32 == 0) {
         const int n = cin / 32, dmax = NBLK >= 6 ? 2 : 4;          // ring registers: 16 D; accumulators: 16 NBLK

@@ -160,20 +160,15 @@ class CroppedSqueezeNet10:
                 self.sq_bg.append(sq.contiguous())
         self._cap = 0
         self._buf = None
-        import os
-        # NHWC on the GPU: MIOpen's implicit-GEMM kernels take it natively (+8 % measured); SWK_CHANNELS_LAST=0/1 overrides
-        want = os.environ.get("SWK_CHANNELS_LAST", "1" if dev.type == "cuda" else "0") == "1"
-        self.memory_format = torch.channels_last if want else torch.contiguous_format
+        # channels-last on the GPU: what the library's convolution kernels read and write
+        self.memory_format = torch.channels_last if dev.type == "cuda" else torch.contiguous_format
         if self.memory_format == torch.channels_last:
             model.to(memory_format=torch.channels_last)
-        # 1x1 convolutions by the library's own fused kernel (SWK_FUSED_1X1=0: through MIOpen + the placement kernel)
-        self.fused_1x1 = os.environ.get("SWK_FUSED_1X1", "1") == "1"
-        self.fused_3x3 = os.environ.get("SWK_FUSED_3X3", "1") == "1"
-        # wide 3x3 expands (fire4..9) by Winograd F(2x2, 3x3) (csrc/cnn_wino3x3.hip); SWK_WINOGRAD_3X3=0: the direct kernel
-        self.fused_wino = os.environ.get("SWK_WINOGRAD_3X3", "1") == "1"
-        self.fused_conv1 = os.environ.get("SWK_FUSED_CONV1", "1") == "1"
+        # The two cross-checks the tests keep: own_kernels = False routes every convolution through MIOpen (+ the placement kernel),
+        # winograd = False runs the 3x3 expands on the direct kernel (csrc/cnn_conv3x3.hip) instead of F(2x2, 3x3).
+        self.own_kernels = os.environ.get("SWK_OWN_CNN_KERNELS", "1") == "1"
+        self.winograd = True
         self._w1 = None
-        self.wino_cin = tuple(int(c) for c in os.environ.get("SWK_WINOGRAD_CIN", "16,32,48,64").split(","))
         self._wt3 = {}
         self._ww3 = {}
 
@@ -187,16 +182,16 @@ class CroppedSqueezeNet10:
         side = (self.IN_HI - self.IN_LO + 1 - 7) // 2 + 1
         executed = useful = side * side * c1.out_channels * c1.in_channels * 49
         last_n = None
-        on_gpu = self.ring_sum.is_cuda and self.memory_format == torch.channels_last
+        on_gpu = self.ring_sum.is_cuda and self.memory_format == torch.channels_last and self.own_kernels
         for kind, layer, tile, off, n, pad, crop in self.plan:
             if kind != "fire":
                 continue
             t = tile.shape[2] + pad[0] + pad[1]
             sq, e1, e3 = layer.squeeze, layer.expand1x1, layer.expand3x3
             executed += n * n * sq.out_channels * sq.in_channels
-            e1_side = n if (on_gpu and self.fused_1x1) else t      # the fused kernel only computes the outputs that depend on the segment
+            e1_side = n if on_gpu else t      # the fused kernel only computes the outputs that depend on the segment
             executed += e1_side * e1_side * e1.out_channels * e1.in_channels
-            wino = on_gpu and self.fused_3x3 and self.fused_wino and e3.out_channels == 4 * e3.in_channels and e3.in_channels in self.wino_cin
+            wino = on_gpu and self.winograd and e3.out_channels == 4 * e3.in_channels and e3.in_channels in (16, 32, 48, 64)
             if wino:
                 tiles = ((t - 2 + 1) // 2) ** 2
                 executed += tiles * 16 * e3.out_channels * e3.in_channels
@@ -319,7 +314,7 @@ class CroppedSqueezeNet10:
         def conv3x3(src, j, conv, dest, off, c_off):
             src = nhwc(src)
             cin, cout = conv.in_channels, conv.out_channels
-            if self.fused_wino and cout == 4 * cin and cin in self.wino_cin and k * src.shape[2] * src.shape[2] * cin * 4 < (1 << 32):
+            if self.winograd and cout == 4 * cin and cin in (16, 32, 48, 64) and k * src.shape[2] * src.shape[2] * cin * 4 < (1 << 32):
                 ww = self._ww3.get(j)
                 if ww is None:       # G g G^T in the kernel's operand layout, once per layer (host code of the library)
                     w = conv.weight.detach().to("cpu", torch.float32).contiguous()
@@ -353,7 +348,7 @@ class CroppedSqueezeNet10:
         a, b = self.pool1_slice
         c1buf = aux["conv1"][rows]
         side = tiles.shape[2]
-        if self.fused_conv1 and conv1.out_channels == 96 and side % 2 == 0 and 2 * (b - 1) + 8 <= side:
+        if self.own_kernels and conv1.out_channels == 96 and side % 2 == 0 and 2 * (b - 1) + 8 <= side:
             # conv1 + bias + ReLU on the rows the first pool reads, one kernel (csrc/cnn_conv1.hip)
             if self._w1 is None:
                 self._w1 = conv1.weight.detach().contiguous(memory_format=torch.contiguous_format).clone()
@@ -381,7 +376,7 @@ class CroppedSqueezeNet10:
                 dest, doff = live[j][rows], 0
             else:
                 dest, doff = bufs[j + 1][rows], self.plan[j + 1][3]
-            if self.fused_1x1:
+            if self.own_kernels:
                 # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
                 # (csrc/cnn_conv1x1.hip)
                 conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
@@ -392,7 +387,7 @@ class CroppedSqueezeNet10:
                 place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
                 e1 = conv2d(sq, layer.expand1x1.weight, None)
                 place(e1, layer.expand1x1.bias, dest, c, cn, doff, 0)
-            if self.fused_3x3:
+            if self.own_kernels:
                 # the 3x3 expand (valid convolution over the squeeze tile) likewise (csrc/cnn_conv3x3.hip)
                 conv3x3(sq, j, layer.expand3x3, dest, doff, c1)
             else:

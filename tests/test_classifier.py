@@ -312,7 +312,10 @@ def test_fused_conv1x1_kernel_against_torch():
         (4, 512, 64, 9, 0, 9, 13, 2, 64, 0), (6, 16, 64, 12, 1, 10, 10, 0, 128, 0), (3, 32, 128, 16, 1, 14, 17, 0, 256, 0),
         (2, 48, 192, 14, 1, 12, 12, 0, 384, 0), (3, 64, 256, 18, 1, 16, 19, 2, 512, 0), (1, 64, 96, 7, 2, 3, 5, 1, 160, 60),
         (9, 16, 4, 5, 0, 5, 5, 0, 8, 4), (3, 80, 40, 6, 1, 5, 6, 1, 40, 0), (2, 384, 64, 14, 0, 14, 18, 2, 64, 0),
-        (2, 192, 24, 7, 0, 7, 7, 0, 24, 0), (37, 32, 128, 3, 0, 3, 3, 0, 128, 0)]
+        (2, 192, 24, 7, 0, 7, 7, 0, 24, 0), (37, 32, 128, 3, 0, 3, 3, 0, 128, 0),
+        # the workgroup size follows the number of 32-pixel row tiles (4, 8 or 16 waves): batches that take the 8- and the 16-wave kernels
+        (700, 96, 16, 8, 0, 8, 8, 0, 16, 0), (1400, 16, 64, 10, 1, 8, 8, 0, 128, 64), (160, 48, 192, 12, 0, 12, 12, 0, 384, 0),
+        (300, 48, 192, 12, 0, 12, 12, 0, 384, 192), (330, 512, 64, 9, 0, 9, 11, 1, 64, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for n, cin, cout, sh, crop, size, dH, off, dC, c_off in cases:
         x = torch.randn((n, cin, sh, sh), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -358,14 +361,13 @@ def test_own_kernels_match_miopen_path_at_bench_batch(tmp_path):
         x = torch.randn((rows, 3, 40, 40), generator=g).cuda()
         with torch.no_grad():
             own = net(x).clone()
-            flags = (net.fused_conv1, net.fused_1x1, net.fused_3x3, net.fused_wino)
             try:
-                net.fused_wino = False
+                net.winograd = False                     # the direct 3x3 kernel instead of F(2x2, 3x3)
                 direct = net(x).clone()
-                net.fused_conv1 = net.fused_1x1 = net.fused_3x3 = False
+                net.own_kernels = False                  # every convolution through MIOpen + the placement kernel
                 miopen = net(x).clone()
             finally:
-                net.fused_conv1, net.fused_1x1, net.fused_3x3, net.fused_wino = flags
+                net.own_kernels, net.winograd = True, True
         scale = float(miopen.abs().max()) + 1e-6
         assert float((own - miopen).abs().max()) <= 2e-5 * max(scale, 1.0), rows
         assert float((direct - miopen).abs().max()) <= 2e-5 * max(scale, 1.0), rows
