@@ -74,10 +74,15 @@ class RoiFrame:
         # pixels that live in a reader's block are handed out as a copy: the block is reused two windows later
         return out.copy() if self.block is not None else out
 
-    def detach(self):
-        """Private copy of the pixels: the block they live in is about to be reused."""
-        self.roi = self.roi.copy()
+    def detach(self, spare=None):
+        """Private copy of the pixels: the block they live in is about to be reused.  spare: a list of arrays of the right shape that
+        earlier detached frames have given back (fresh pages are expensive; a long video recycles a handful of buffers)."""
+        buf = spare.pop() if spare else np.empty_like(self.roi)
+        np.copyto(buf, self.roi)
+        self.roi = buf
         self.block, self.slot = None, -1
+        if spare is not None:
+            weakref.finalize(self, spare.append, buf)
 
     def as_full_frame(self, fill=128):
         """A full-size ndarray with the stored rectangle pasted in (ROI-mask generation reads the first frame's crop region)."""
@@ -137,7 +142,8 @@ def write_roi_stream(path, frames, crop_region, fps=30.0, min_seg_size=(24, 24))
 class RoiStreamReader:
     """FrameReader over a ROI stream file (io_video.py:13-82 bookkeeping).  prefetch=True reads the next window ahead in a thread."""
 
-    BLOCKS = 3
+    BLOCKS = 6          # a block is reused five windows later: by then few of its frames are still referenced (tracks last 1-2 windows)
+    MAX_BLOCKS = 32     # the ring grows when most frames of the block in turn are still in use (a caller that reads many windows ahead)
 
     def __init__(self, path, start=0, end=0, prefetch=True, device=0):
         self.filepath = path
@@ -174,8 +180,10 @@ class RoiStreamReader:
         self.device = device
         self._midnight = datetime.datetime.combine(datetime.date.today(), datetime.time())
         self._blocks, self._alive, self._turn = [], [], 0
+        self._spare = []                     # pixel buffers of detached frames that have died since
         self._prefetch = prefetch
-        self._pending = None                 # (first frame number, n, block index, thread)
+        self._pending = None                 # (first frame number, n, block index, "done" event)
+        self._jobs = None                    # queue of the read-ahead thread (started with the first window)
 
     # ---- the reference reader's surface ----
     def frame_number_to_timestamp(self, frame_number):
@@ -216,7 +224,11 @@ class RoiStreamReader:
     def close(self):
         if getattr(self, "_fd", None) is not None:
             if self._pending is not None:
-                self._pending[3].join()
+                self._pending[3].wait()
+                self._pending = None
+            if self._jobs is not None:
+                self._jobs.put(None)
+                self._jobs = None
             os.close(self._fd)
             self._fd = None
 
@@ -228,22 +240,27 @@ class RoiStreamReader:
 
     # ---- a window at a time: one page-locked block in queue order, next window read ahead ----
     def _block(self, n):
+        """The page-locked block the next window goes into (the ring's next one; frames that still live in it get private pixels)."""
         if not self._blocks or self._blocks[0].shape[0] != n:
             self._blocks = [_lib.pinned_empty((n,) + self.roi_shape, np.uint8, device=self.device) for _ in range(self.BLOCKS)]
             self._alive = [[] for _ in range(self.BLOCKS)]
+            self._turn = 0
         b = self._turn
-        self._turn = (b + 1) % self.BLOCKS
-        for ref in self._alive[b]:                       # frames of the window this block held, still referenced somewhere
-            fr = ref()
-            if fr is not None and fr.block is self._blocks[b]:
-                fr.detach()
-        self._alive[b] = []
-        return b
+        live = [fr for fr in (ref() for ref in self._alive[b]) if fr is not None and fr.block is self._blocks[b]]
+        if len(live) > n // 2 and len(self._blocks) < self.MAX_BLOCKS:
+            # most of that window is still in use (its frames wait to be segmented, or sit in long tracks): a new block instead
+            self._blocks.insert(b, _lib.pinned_empty((n,) + self.roi_shape, np.uint8, device=self.device))
+            self._alive.insert(b, [])
+        else:
+            for fr in live:
+                fr.detach(self._spare)
+            self._alive[b] = []
+        self._turn = (b + 1) % len(self._blocks)
+        return self._blocks[b], self._alive[b]
 
-    def _fill(self, b, first, n):
-        """Pixels of frames first .. first + n - 1 into block b, frame k at slot n - 1 - k (the queue's order); nulls are zeros,
+    def _fill(self, block, first, n):
+        """Pixels of frames first .. first + n - 1 into the block, frame k at slot n - 1 - k (the queue's order); nulls are zeros,
         the frame one past the end repeats the last one (get_frame's fallback)."""
-        block = self._blocks[b]
         for k in range(n):
             if self.start_frame <= first + k <= self.end_frame and first + k < self.count:
                 self._read_into(first + k, block[n - 1 - k])
@@ -259,28 +276,49 @@ class RoiStreamReader:
                 else:
                     block[n - 1 - k] = 0
 
+    def _reader_loop(self, jobs):
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            block, first, n, done = job
+            try:
+                self._fill(block, first, n)
+            except BaseException as exc:          # surfaces in get_n_frames
+                done.error = exc
+            done.set()
+
     def _start_prefetch(self, first, n):
         if not self._prefetch or first > self.end_frame:
             self._pending = None
             return
-        b = self._block(n)
-        th = threading.Thread(target=self._fill, args=(b, first, n), daemon=True)
-        th.start()
-        self._pending = (first, n, b, th)
+        if self._jobs is None:
+            import queue
+            self._jobs = queue.Queue()
+            threading.Thread(target=self._reader_loop, args=(self._jobs,), daemon=True).start()
+        block, alive = self._block(n)
+        done = threading.Event()
+        done.error = None
+        self._jobs.put((block, first, n, done))
+        self._pending = (first, n, (block, alive), done)
+
+    def _wait(self, pend):
+        pend[3].wait()
+        if pend[3].error is not None:
+            raise pend[3].error
 
     def get_n_frames(self, n):
         first = self.next_frame_number
         pend = self._pending
         if pend is not None and pend[0] == first and pend[1] == n:
-            pend[3].join()
-            b = pend[2]
+            self._wait(pend)
+            block, alive = pend[2]
         else:
             if pend is not None:
-                pend[3].join()
-            b = self._block(n)
-            self._fill(b, first, n)
+                self._wait(pend)
+            block, alive = self._block(n)
+            self._fill(block, first, n)
         self._pending = None
-        block = self._blocks[b]
         frames, numbers, stamps = [], [], []
         for k in range(n):
             number = self.next_frame_number
@@ -295,7 +333,7 @@ class RoiStreamReader:
                     self.frames_read += 1
                 else:
                     self.read_errors += 1
-            self._alive[b].append(weakref.ref(fr))
+            alive.append(weakref.ref(fr))
             frames.append(fr); numbers.append(num); stamps.append(ts)
         self._start_prefetch(self.next_frame_number, n)
         return frames, numbers, stamps

@@ -62,7 +62,23 @@ def test_blocks_are_recycled_only_after_live_frames_got_their_own_pixels(tmp_pat
         for fr, num, cut in held:                         # frames (and cuts) of every earlier window still show their own pixels
             np.testing.assert_array_equal(fr.roi, clip[num][ya:yb, xa:xb])
             np.testing.assert_array_equal(cut, clip[num][30:60, 40:80])
-    assert held[0][0].block is None and held[5][0].block is not None
+    assert held[5][0].block is not None
+    # ... also once their block has been handed to a later window (the reader rotates RoiStreamReader.BLOCKS of them)
+    more = _clip(21 * 8, seed=4)
+    path2 = write_roi_stream(str(tmp_path / "clip2.swkroi"), more, CROP)
+    r2 = RoiStreamReader(path2)
+    held = []
+    for w in range(8):
+        frames, numbers, _ = r2.get_n_frames(21)
+        held.append((frames[5], numbers[5]))
+        for fr, num in held:
+            np.testing.assert_array_equal(fr.roi, more[num][ya:yb, xa:xb])
+    assert held[0][0].block is None and held[7][0].block is not None
+    spare_before = len(r2._spare)
+    del held, fr, frames
+    import gc
+    gc.collect()
+    assert len(r2._spare) > spare_before            # the private buffers of detached frames come back for reuse
 
 
 def test_queue_uploads_the_readers_block_without_a_copy(tmp_path):

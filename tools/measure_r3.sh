@@ -8,9 +8,10 @@ export TMPDIR=/tmp
 case "$1" in
 a)
   python bench.py > gpurun_out/r3m/default.json 2> gpurun_out/r3m/default.err
-  rocprofv3 --kernel-trace --stats -d gpurun_out/r3m/prof -o r3 -- python3 bench.py --no-cpu-baseline --no-drop-in --steps 2 --warmup 1 > gpurun_out/r3m/prof_bench.json 2> gpurun_out/r3m/prof_bench.err
-  find gpurun_out/r3m/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r3m/r3_kernel_stats_default_bench.csv \;
-  find gpurun_out/r3m/prof -name "*_kernel_trace.csv" -delete; find gpurun_out/r3m/prof -name "*.db" -delete
+  rm -rf gpurun_out/r3m/prof
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3m/prof -- python3 bench.py --no-cpu-baseline --no-drop-in --steps 2 --warmup 1 > gpurun_out/r3m/prof_bench.json 2> gpurun_out/r3m/prof_bench.err
+  cp $(ls gpurun_out/r3m/prof/*/*kernel_stats.csv | head -1) gpurun_out/r3m/r3_kernel_stats_default_bench.csv
+  rm -rf gpurun_out/r3m/prof
   head -12 gpurun_out/r3m/r3_kernel_stats_default_bench.csv
   ;;
 b)
