@@ -149,6 +149,12 @@ int32_t swk_pinned_free(void *p);
  * 21-frame 1080p window's ROI in about half a millisecond). */
 int32_t swk_stage_frames(const uint8_t *const *frames, int32_t count, int64_t row_stride, int32_t y0, int32_t rows, int64_t x_bytes,
                          int64_t row_bytes, uint8_t *dst, int32_t threads);
+/* Host side, no context: `count` boxes cut out of a window's frames in one call -- box i = rows [boxes[4i], boxes[4i+1]) x columns
+ * [boxes[4i+2], boxes[4i+3]) of frame frame_of[i] (frames[f] = first byte of frame f, row_stride bytes per row, pixel_bytes per
+ * pixel), copied densely to out + offsets[i].  The segment images of extract_segment_images (image_filtering.py:338-369) for
+ * frames whose memory is reused (the ROI-stream reader's blocks): the segments then hold their crops, not the frames. */
+int32_t swk_cut_boxes(const uint8_t *const *frames, int32_t nframes, int64_t row_stride, int32_t pixel_bytes, int32_t count,
+                      const int32_t *frame_of, const int32_t *boxes, const int64_t *offsets, uint8_t *out);
 /* Device memory on the context's GPU for outputs the caller wants to keep there (swk_output with planes_on_device, or
  * mem = SWK_MEM_DEVICE), and a synchronous copy of a piece of it to host memory.  The library never frees such a buffer
  * by itself; swk_device_free waits for the context's stream first. */

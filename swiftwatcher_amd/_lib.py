@@ -120,6 +120,7 @@ _SIGS = {
     "swk_roi_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "swk_pinned_alloc": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     "swk_pinned_free": (ctypes.c_int32, [ctypes.c_void_p]),
+    "swk_cut_boxes": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_stage_frames": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_enable": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_prof_reset": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -569,6 +570,29 @@ def stage_frames(frames, y0, y1, x0, x1, dst, threads=4):
     rc = load().swk_stage_frames(ptrs, len(frames), f0.strides[0], y0, y1 - y0, x0 * px, (x1 - x0) * px, dst.ctypes.data, threads)
     if rc:
         raise SwkError("swk_stage_frames failed (%d)" % rc)
+
+
+def cut_boxes(arrays, frame_of, boxes):
+    """swk_cut_boxes: boxes (count, 4) int32 rows [r0, r1) x columns [c0, c1) of arrays[frame_of[i]] (equally shaped, row-contiguous
+    uint8 arrays), copied densely into ONE new buffer.  Returns (buffer, offsets int64 (count,))."""
+    a0 = arrays[0]
+    px = a0.strides[1]
+    h = np.maximum(boxes[:, 1] - boxes[:, 0], 0).astype(np.int64)
+    w = np.maximum(boxes[:, 3] - boxes[:, 2], 0).astype(np.int64)
+    sizes = h * w * px
+    offsets = np.zeros(len(boxes), np.int64)
+    if len(boxes) > 1:
+        np.cumsum(sizes[:-1], out=offsets[1:])
+    out = np.empty(int(sizes.sum()) if len(boxes) else 0, np.uint8)
+    if len(boxes):
+        ptrs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        fo = np.ascontiguousarray(frame_of, np.int32)
+        bx = np.ascontiguousarray(boxes, np.int32)
+        rc = load().swk_cut_boxes(ptrs, len(arrays), a0.strides[0], px, len(boxes), fo.ctypes.data, bx.ctypes.data, offsets.ctypes.data,
+                                  out.ctypes.data)
+        if rc:
+            raise SwkError("swk_cut_boxes failed (%d)" % rc)
+    return out, offsets
 
 
 class DevicePlanes:

@@ -104,5 +104,24 @@ int32_t swk_stage_frames(const uint8_t *const *frames, int32_t count, int64_t ro
     return SWK_OK;
 }
 
+// Segment images of a window cut in one go (extract_segment_images, image_filtering.py:338-369, for frames that must not be kept alive
+// by their segments: the ROI-stream reader's page-locked blocks are reused): box i = rows [boxes[4i], boxes[4i+1]) x columns
+// [boxes[4i+2], boxes[4i+3]) of frame frame_of[i], copied densely to out + offsets[i].
+int32_t swk_cut_boxes(const uint8_t *const *frames, int32_t nframes, int64_t row_stride, int32_t pixel_bytes, int32_t count,
+                      const int32_t *frame_of, const int32_t *boxes, const int64_t *offsets, uint8_t *out)
+{
+    if (!frames || !frame_of || !boxes || !offsets || !out || count < 0 || nframes < 1 || pixel_bytes < 1) return SWK_ERR_ARG;
+    for (int i = 0; i < count; ++i) {
+        const int f = frame_of[i], r0 = boxes[4 * i], r1 = boxes[4 * i + 1], c0 = boxes[4 * i + 2], c1 = boxes[4 * i + 3];
+        if (f < 0 || f >= nframes || !frames[f] || r0 < 0 || c0 < 0) return SWK_ERR_ARG;
+        if (r1 <= r0 || c1 <= c0) continue;
+        const int64_t rowb = (int64_t)(c1 - c0) * pixel_bytes;
+        const uint8_t *src = frames[f] + (int64_t)r0 * row_stride + (int64_t)c0 * pixel_bytes;
+        uint8_t *dst = out + offsets[i];
+        for (int r = 0; r < r1 - r0; ++r) memcpy(dst + (int64_t)r * rowb, src + (int64_t)r * row_stride, (size_t)rowb);
+    }
+    return SWK_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -30,6 +30,33 @@ class _Cut(tuple):
     __slots__ = ()
 
 
+class _Crop(tuple):
+    """(buffer, offset, rows, columns, trailing shape) of a segment image that sits in its window's crop buffer (frames of a ROI-stream
+    reader: their memory is reused, so the window's crops are copied out in one call and the segments do not hold the frames)."""
+    __slots__ = ()
+
+
+def _window_crops(frames, nseg, live, min_seg_size, crop_region):
+    """One buffer with every segment image of the window (extract_segment_images' boxes, image_filtering.py:345-366), for RoiFrames."""
+    first = frames[0]
+    Hf, Wf = first.shape[:2]
+    oy0, ox0 = first.origin
+    r0, c0, r1, c1 = (live[k].astype(np.int64) for k in ("r0", "c0", "r1", "c1"))
+    d = np.maximum(int(min_seg_size[0]) - (r1 - r0), 0)
+    r0, r1 = r0 - d // 2, r1 + (d - d // 2)
+    d = np.maximum(int(min_seg_size[1]) - (c1 - c0), 0)
+    c0, c1 = c0 - d // 2, c1 + (d - d // 2)
+    oy, ox = crop_region[0][1], crop_region[0][0]
+    boxes = np.stack([np.clip(r0 + oy, 0, Hf) - oy0, np.clip(r1 + oy, 0, Hf) - oy0,
+                      np.clip(c0 + ox, 0, Wf) - ox0, np.clip(c1 + ox, 0, Wf) - ox0], 1)
+    h, w = first.roi.shape[:2]
+    if len(boxes) and (boxes[:, 0].min() < 0 or boxes[:, 2].min() < 0 or boxes[:, 1].max() > h or boxes[:, 3].max() > w):
+        raise ValueError("a segment box leaves the rectangle the ROI stream holds")
+    frame_of = np.repeat(np.arange(len(frames)), nseg)
+    buf, offsets = _lib.cut_boxes([f.roi for f in frames], frame_of, boxes)
+    return buf, offsets.tolist(), np.maximum(boxes[:, 1] - boxes[:, 0], 0).tolist(), np.maximum(boxes[:, 3] - boxes[:, 2], 0).tolist()
+
+
 def window_segments(segs, nseg, slots, min_seg_size, crop_region, batch=None):
     """Segment objects of a whole batch_run at once: slots = the Frame objects in the batch's frame order; segs / nseg = its
     region records.  The same attributes Segment.__init__ sets (label, bbox, centroid = sum / area in float64, area), made
@@ -42,6 +69,11 @@ def window_segments(segs, nseg, slots, min_seg_size, crop_region, batch=None):
                (live["sum_r"].astype(np.float64) / fa).tolist(), (live["sum_c"].astype(np.float64) / fa).tolist(), area.tolist())
     new = Segment.__new__
     k = 0
+    crops = None
+    if len(slots) and hasattr(slots[0].frame, "roi"):
+        buf, offs, hs, ws = _window_crops([s.frame for s in slots], nseg, live, min_seg_size, crop_region)
+        tail = tuple(slots[0].frame.roi.shape[2:])
+        crops = (_Crop((buf, o, h, w, tail)) for o, h, w in zip(offs, hs, ws))
     for slot, count in zip(slots, nseg.tolist()):
         number, stamp, frame = slot.frame_number, slot.timestamp, slot.frame
         out = []
@@ -49,7 +81,8 @@ def window_segments(segs, nseg, slots, min_seg_size, crop_region, batch=None):
             lab, r0, c0, r1, c1, cy, cx, ar = next(rows)
             s = new(Segment)
             bbox = (r0, c0, r1, c1)
-            s.__dict__ = {"parent_frame_number": number, "parent_timestamp": stamp, "_image": _Cut((frame, bbox, min_seg_size, crop_region)),
+            s.__dict__ = {"parent_frame_number": number, "parent_timestamp": stamp,
+                          "_image": next(crops) if crops is not None else _Cut((frame, bbox, min_seg_size, crop_region)),
                           "segment_history": [], "status": None, "label": lab, "bbox": bbox, "centroid": (cy, cx), "area": ar,
                           "_batch": batch, "_index": k}
             if batch is None:
@@ -82,6 +115,10 @@ class Segment:
         if type(im) is _Cut:                 # (frame, bbox, min_seg_size, crop_region): the view is made on first read
             r0, r1, c0, c1 = img.segment_crop_box(im[1], im[0].shape, im[2], im[3])
             im = self._image = im[0][r0:r1, c0:c1]
+        elif type(im) is _Crop:              # (buffer, offset, rows, columns, trailing shape): a view of the window's crop buffer
+            buf, off, h, w, tail = im
+            count = h * w * int(np.prod(tail, dtype=np.int64))
+            im = self._image = buf[off:off + count].reshape((h, w) + tail)
         elif callable(im):
             im = self._image = im()
         return im

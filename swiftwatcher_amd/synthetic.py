@@ -9,8 +9,8 @@ P2 = dict(Hc=212, Wc=424, bird_len=(30, 50), bird_wid=(12, 20), birds=12)     # 
 P1 = dict(Hc=107, Wc=214, bird_len=(10, 15), bird_wid=(4, 7), birds=12)       # w = 172 px chimney, 1080p
 # 4K: w = 680 px chimney.  The reference's lambda is fixed at 0.01 (image_filtering.py:256) whatever the ROI's size, so at four times the
 # pixels the sparse term is dearer against the nuclear norm: birds scaled up with the frame (60-100 x 24-40 px) are absorbed into the
-# low-rank part (0.7-1.8 segments per frame found, oracle and HIP path alike).  SURVEY 8d asks for about 12 segments per frame: 14 birds
-# of the 1080p pixel size give 12.1 per frame at the CLI's queue of 21 (oracle).
+# low-rank part (0.7-1.8 segments per frame found, by the CPU restatement and the HIP path alike).  SURVEY 8d asks for about 12 segments per frame: 14 birds
+# of the 1080p pixel size give 12.1 per frame at the CLI's queue of 21.
 P3 = dict(Hc=425, Wc=850, bird_len=(30, 50), bird_wid=(12, 20), birds=14)
 
 
