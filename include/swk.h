@@ -92,7 +92,9 @@ typedef struct swk_segment {
  *   frames + (w*n + j)*frame_stride, pixel (r, c) of its ROI at
  *   + (y0 + r)*row_stride + (x0 + c)*channels.
  * Passing whole 1080p frames with (x0, y0, Hc, Wc) = crop_region reproduces
- * crop_frame() (image_filtering.py:199-203); passing pre-cropped ROIs uses x0=y0=0. */
+ * crop_frame() (image_filtering.py:199-203); passing pre-cropped ROIs uses x0=y0=0.
+ * frame_stride may be negative: `frames` is then the LAST frame in memory (a window that lies in the order it was read,
+ * oldest first, is handed over without reversing it: queue position 0 = the newest = the last one read). */
 typedef struct swk_input {
     const uint8_t *frames;
     int32_t mem;            /* SWK_MEM_HOST / SWK_MEM_DEVICE */

@@ -374,7 +374,7 @@ class Context:
         self._check(self._lib.swk_batch_run(self._h, ctypes.byref(inp), ctypes.byref(params), ctypes.byref(out)))
 
     def batch_run(self, frames, nwin, n, crop=None, params=None, stages=STAGES, want_A=False, want_E=False, seg_cap=255,
-                  device_stages=False):
+                  device_stages=False, reverse_frames=False):
         """Host-buffer convenience wrapper.
 
         frames: u8 array (nwin*n, H, W, 3) or (nwin*n, H, W), C-contiguous in the last two/three axes
@@ -383,6 +383,8 @@ class Context:
         'nseg' (nwin*n,), 'segs' structured array (nwin*n, seg_cap), optionally 'A'/'E' (nwin, P, n).
         device_stages=True: the stage stacks stay on the GPU -- res['planes'] is a DevicePlanes whose read(stage, frame)
         copies one image to the host when somebody asks for it (swk_output.planes_on_device).
+        reverse_frames=True: frame j of the batch is frames[F - 1 - j] (negative frame stride): a window that lies in memory in
+        the order it was read becomes a queue (position 0 = newest) without being reversed.
         """
         params = params or default_params()
         F = nwin * n
@@ -397,8 +399,9 @@ class Context:
         x0, y0, Wc, Hc = crop if crop is not None else (0, 0, W, H)
         if x0 < 0 or y0 < 0 or x0 + Wc > W or y0 + Hc > H:
             raise ValueError("crop rectangle outside the frame")
-        inp = Input(frames=frames.ctypes.data, mem=MEM_HOST, channels=ch, nwin=nwin, n=n, Hc=Hc, Wc=Wc,
-                    x0=x0, y0=y0, frame_stride=frames.strides[0], row_stride=frames.strides[1])
+        inp = Input(frames=frames.ctypes.data + ((F - 1) * frames.strides[0] if reverse_frames else 0), mem=MEM_HOST, channels=ch,
+                    nwin=nwin, n=n, Hc=Hc, Wc=Wc, x0=x0, y0=y0,
+                    frame_stride=-frames.strides[0] if reverse_frames else frames.strides[0], row_stride=frames.strides[1])
         res = {}
         out = Output(mem=MEM_HOST, seg_cap=seg_cap)
         if device_stages and stages:

@@ -797,17 +797,20 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         NEED(ctx, SL_ROI, plane * in->channels, roi);
         Timed t(ctx, SWK_K_COPY);
         bool whole = false;
+        const int64_t afs = fs < 0 ? -fs : fs;
         const size_t rowb = (size_t)W * in->channels;
         if (x0 == 0 && (size_t)rs == rowb && fs == (int64_t)H * rs) {
             // pre-cropped, densely packed ROI frames: one copy for the whole batch
             HIPCHK(ctx, hipMemcpyAsync(roi, in->frames + (int64_t)y0 * rs, plane * in->channels, hipMemcpyHostToDevice, s));
-        } else if (rs >= (int64_t)(x0 + W) * in->channels && rs % in->channels == 0 && fs % rs == 0 && fs >= (int64_t)(y0 + H) * rs &&
-                   (size_t)F * (size_t)fs <= 2 * plane * in->channels) {
+        } else if (rs >= (int64_t)(x0 + W) * in->channels && rs % in->channels == 0 && afs % rs == 0 && afs >= (int64_t)(y0 + H) * rs &&
+                   (size_t)F * (size_t)afs <= 2 * plane * in->channels) {
             // ROI frames with a margin around them (FrameQueue stages the crop plus the half minimum segment size, so that
             // segment boxes can grow into it like they grow into the full frame, image_filtering.py:338-369): the whole
-            // buffer in one copy; the kernels read the ROI at (x0, y0) of the device copy
-            NEED(ctx, SL_ROI, (size_t)F * (size_t)fs, roi);
-            HIPCHK(ctx, hipMemcpyAsync(roi, in->frames, (size_t)F * (size_t)fs, hipMemcpyHostToDevice, s));
+            // buffer in one copy; the kernels read the ROI at (x0, y0) of the device copy.  A NEGATIVE frame stride (queue
+            // position 0 = the LAST frame in memory: a reader's block in file order) is copied as it lies and read backwards.
+            NEED(ctx, SL_ROI, (size_t)F * (size_t)afs, roi);
+            const uint8_t *lowest = fs < 0 ? in->frames + (int64_t)(F - 1) * fs : in->frames;
+            HIPCHK(ctx, hipMemcpyAsync(roi, lowest, (size_t)F * (size_t)afs, hipMemcpyHostToDevice, s));
             whole = true;
         } else if (x0 == 0 && (size_t)rs == rowb) {
             for (int f = 0; f < F; ++f)                    // full-width rows: one contiguous block per frame
@@ -819,7 +822,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
                                              in->frames + (int64_t)f * fs + (int64_t)y0 * rs + (int64_t)x0 * in->channels, (size_t)rs,
                                              rowb, H, hipMemcpyHostToDevice, s));
         }
-        dframes = roi;
+        dframes = (whole && fs < 0) ? roi + (int64_t)(F - 1) * afs : roi;
         if (!whole) { fs = (int64_t)P * in->channels; rs = (int64_t)rowb; x0 = 0; y0 = 0; }
     }
     // ---- stage buffers (caller's device buffers are written in place) ----
@@ -900,7 +903,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
         swk_ctx::LastBatch &lb = ctx->last;
         lb.frames = dframes; lb.fs = fs; lb.rs = rs;
         lb.nwin = in->nwin; lb.n = in->n; lb.Hc = H; lb.Wc = W; lb.x0 = x0; lb.y0 = y0;
-        lb.frame_h = (int)(fs / rs); lb.frame_w = (int)(rs / 3);
+        lb.frame_h = (int)((fs < 0 ? -fs : fs) / rs); lb.frame_w = (int)(rs / 3);
         lb.segs = dsegs; lb.nseg = dnseg; lb.cap = cap;
         lb.total = -1;
         if (!dev_out && out->nseg) {
@@ -1100,7 +1103,7 @@ int32_t swk_segment_inputs(swk_ctx *ctx, const swk_input *in, int32_t frame_h, i
         (channels_last != 0 && channels_last != 1) ||
         frame_h < 1 || frame_w < 1 || min_h < 1 || min_w < 1 || min_h > 512 || min_w > 512 ||
         in->x0 < 0 || in->y0 < 0 || in->x0 + in->Wc > frame_w || in->y0 + in->Hc > frame_h ||
-        in->row_stride < (int64_t)frame_w * 3 || in->frame_stride < in->row_stride * frame_h)
+        in->row_stride < (int64_t)frame_w * 3 || (in->frame_stride < 0 ? -in->frame_stride : in->frame_stride) < in->row_stride * frame_h)
         return fail(ctx, SWK_ERR_ARG, "bad geometry");
     return segment_inputs_impl(ctx, in->frames, in->frame_stride, in->row_stride, (int)F64, in->x0, in->y0, frame_h, frame_w, segs, nseg,
                                seg_cap, min_h, min_w, mean, std_, pad, channels_last != 0, first, net_cap, net, seg_frame, total, skipped);

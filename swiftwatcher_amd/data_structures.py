@@ -310,11 +310,12 @@ class FrameQueue(deque):
         segment crops, one swk_batch_run for the whole window."""
         if "crop" not in self[0].processed_frames:
             raise RuntimeError("preprocess_queue must run before segment_queue")
-        stack, (rx, ry), (Hc, Wc) = self._stage_window(min_seg_size, crop_region)
+        stack, (rx, ry), (Hc, Wc), backwards = self._stage_window(min_seg_size, crop_region)
         n = stack.shape[0]
         ctx = _lib.default_context(self.device)
         stages = tuple(STAGE_KEYS) if self.keep_stages else ()
-        res = ctx.batch_run(stack, 1, n, crop=(rx, ry, Wc, Hc), params=self.params, stages=stages, device_stages=True)
+        res = ctx.batch_run(stack, 1, n, crop=(rx, ry, Wc, Hc), params=self.params, stages=stages, device_stages=True,
+                            reverse_frames=backwards)
         generation = ctx.generation
         self.last_iters = int(res["iters"][0])
         nseg = res["nseg"]
@@ -340,7 +341,7 @@ class FrameQueue(deque):
 
 def stack_frames(frames, crop_region, min_seg_size, buffer):
     """frames (in the batch's frame order) -> (stack (F, Hm, Wm[, C]) uint8 in page-locked memory, (x, y) of the ROI inside a stacked
-    frame, ROI (Hc, Wc)).  Full decoded frames are cropped to the ROI plus its margin into buffer(shape) (swk_stage_frames).
+    frame, ROI (Hc, Wc), reversed: the stack holds the frames in the opposite order).  Full decoded frames are cropped to the ROI plus its margin into buffer(shape) (swk_stage_frames).
     RoiFrames of a ROI-stream reader (io_roi_stream.py) already ARE that rectangle: when they sit, in this order, in one of the
     reader's page-locked blocks, the block itself is the stack -- no copy at all."""
     first = frames[0]
@@ -351,14 +352,17 @@ def stack_frames(frames, crop_region, min_seg_size, buffer):
         if ya < oy or xa < ox or yb > oy + h or xb > ox + w:
             raise ValueError("the ROI stream does not hold the crop region plus its margin")
         block = first.block
+        last = len(frames) - 1
+        if block is not None and block.shape[0] == len(frames) and all(f.block is block and f.slot == last - i for i, f in enumerate(frames)):
+            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), True          # the block lies in file order: read it backwards
         if block is not None and block.shape[0] == len(frames) and all(f.block is block and f.slot == i for i, f in enumerate(frames)):
-            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0)
+            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), False
         stack = buffer((len(frames), yb - ya, xb - xa) + first.shape[2:])
         _lib.stage_frames([f.roi for f in frames], ya - oy, yb - oy, xa - ox, xb - ox, stack)
-        return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
+        return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0), False
     stack = buffer((len(frames), yb - ya, xb - xa) + first.shape[2:])
     _lib.stage_frames(frames, ya, yb, xa, xb, stack)
-    return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0)
+    return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0), False
 
 
 def _margin_rect(frame_shape, crop_region, min_seg_size):
@@ -386,8 +390,8 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
         if len(frames) != n:
             raise ValueError("every window needs the same number of frames")
         ordered.extend(frames[::-1])                         # queue index 0 = newest = last frame read (:134)
-    stack, (rx, ry), (Hc, Wc) = stack_frames(ordered, crop_region, min_seg_size, ctx.staging)
-    res = ctx.batch_run(stack, len(windows), n, crop=(rx, ry, Wc, Hc), params=params, stages=())
+    stack, (rx, ry), (Hc, Wc), backwards = stack_frames(ordered, crop_region, min_seg_size, ctx.staging)
+    res = ctx.batch_run(stack, len(windows), n, crop=(rx, ry, Wc, Hc), params=params, stages=(), reverse_frames=backwards)
     nseg = res["nseg"]
     if np.any(nseg > res["segs"].shape[1]):
         raise _lib.SwkError("more regions in a frame than seg_cap")

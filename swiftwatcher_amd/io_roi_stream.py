@@ -14,11 +14,12 @@ that rule, exactly like VideoReader / HDF5Reader.  What it hands out are RoiFram
 (frame[y0:y1, x0:x1] in full-frame coordinates, which is all crop_frame and extract_segment_images do) but hold only the stored
 rectangle.
 
-get_n_frames(n) delivers a window as views of ONE page-locked block laid out in the queue's order (FrameQueue pushes with
-appendleft: the last frame read is queue position 0), so FrameQueue.segment_queue uploads that block as it is -- no staging copy --
-and a background thread fills the next window's block from the (memory-mapped) file while the current window is classified and
-tracked.  A block is reused two windows later; Frame objects still alive then (the tracker's cached frame, segments kept in
-events) get a private copy of their pixels first.
+get_n_frames(n) delivers a window as views of ONE page-locked block in the order of the file (one read per window).  FrameQueue
+pushes with appendleft -- the last frame read is queue position 0 -- and hands the block to the library as it is, with a negative
+frame stride: no staging copy, no reversal.  A background thread fills the next window's block while the current window is classified
+and tracked.  A block is reused a few windows later; frames still alive then (the tracker's cached frame) get a private copy of their
+pixels first, and a window's segment images are cut into one buffer of their own when the window is segmented, so segments kept in
+long tracks or in events do not hold frames.
 """
 import datetime
 import json
@@ -259,22 +260,27 @@ class RoiStreamReader:
         return self._blocks[b], self._alive[b]
 
     def _fill(self, block, first, n):
-        """Pixels of frames first .. first + n - 1 into the block, frame k at slot n - 1 - k (the queue's order); nulls are zeros,
-        the frame one past the end repeats the last one (get_frame's fallback)."""
-        for k in range(n):
-            if self.start_frame <= first + k <= self.end_frame and first + k < self.count:
-                self._read_into(first + k, block[n - 1 - k])
+        """Pixels of frames first .. first + n - 1 into the block, frame k at slot k (the order of the file: ONE read for the window's
+        real frames; FrameQueue hands the block over with a negative frame stride, queue position 0 = slot n - 1); nulls are zeros, the
+        frame one past the end repeats the last one (get_frame's fallback)."""
+        real = [k for k in range(n) if self.start_frame <= first + k <= self.end_frame and first + k < self.count]
+        if real:
+            k0, k1 = real[0], real[-1]
+            want = (k1 - k0 + 1) * self._frame_bytes
+            got = os.preadv(self._fd, [memoryview(block[k0:k1 + 1]).cast("B")], self._hdr + (first + k0) * self._frame_bytes)
+            if got != want:
+                raise IOError("short read of frames %d..%d of %s" % (first + k0, first + k1, self.filepath))
         for k in range(n):
             number = first + k
             if not self.start_frame <= number <= self.end_frame:
-                block[n - 1 - k] = 0
+                block[k] = 0
             elif number >= self.count:
                 if k > 0 and number - 1 < self.count:
-                    block[n - 1 - k] = block[n - k]
+                    block[k] = block[k - 1]
                 elif self.last_read_frame is not None:
-                    block[n - 1 - k] = self.last_read_frame.roi
+                    block[k] = self.last_read_frame.roi
                 else:
-                    block[n - 1 - k] = 0
+                    block[k] = 0
 
     def _reader_loop(self, jobs):
         while True:
@@ -323,9 +329,9 @@ class RoiStreamReader:
         for k in range(n):
             number = self.next_frame_number
             if not self.start_frame <= number <= self.end_frame:
-                fr, num, ts = RoiFrame(block[n - 1 - k], self.origin, self.full_shape, block, n - 1 - k), -1, "00:00:00.000"
+                fr, num, ts = RoiFrame(block[k], self.origin, self.full_shape, block, k), -1, "00:00:00.000"
             else:
-                fr = RoiFrame(block[n - 1 - k], self.origin, self.full_shape, block, n - 1 - k)
+                fr = RoiFrame(block[k], self.origin, self.full_shape, block, k)
                 num, ts = number, self.frame_number_to_timestamp(number)
                 self.next_frame_number += 1
                 if number < self.count:

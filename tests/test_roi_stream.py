@@ -35,8 +35,8 @@ def test_reader_bookkeeping_equals_array_reader(tmp_path, total, n, prefetch):
             np.testing.assert_array_equal(y[30:90, 40:160], x[30:90, 40:160])               # crop_frame
             np.testing.assert_array_equal(y[18:42, 150:172], x[18:42, 150:172])             # a segment box grown into the margin
             np.testing.assert_array_equal(y.roi, x[ya:yb, xa:xb])
-        # the window sits in ONE block in the queue's order (appendleft: last frame read = position 0)
-        assert all(f.block is fb[0].block and f.slot == n - 1 - k for k, f in enumerate(fb))
+        # the window sits in ONE block in the order of the file (FrameQueue reads it backwards: last frame read = position 0)
+        assert all(f.block is fb[0].block and f.slot == k for k, f in enumerate(fb))
     # single-frame interface
     c = RoiStreamReader(path, prefetch=False)
     f0 = c.read_frame(0, increment=False)
@@ -91,19 +91,22 @@ def test_queue_uploads_the_readers_block_without_a_copy(tmp_path):
     frames, numbers, stamps = r.get_n_frames(21)
     q.push_list_of_frames(frames, numbers, stamps)
     made = []
-    stack, (rx, ry), (Hc, Wc) = stack_frames(q.get_queue(), CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
-    assert stack is frames[0].block and not made and (rx, ry, Hc, Wc) == (12, 12, 60, 120)
-    for pos in range(21):
-        np.testing.assert_array_equal(stack[pos][ry:ry + Hc, rx:rx + Wc], clip[20 - pos][30:90, 40:160])
+    stack, (rx, ry), (Hc, Wc), backwards = stack_frames(q.get_queue(), CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert stack is frames[0].block and backwards and not made and (rx, ry, Hc, Wc) == (12, 12, 60, 120)
+    for pos in range(21):                                  # queue position pos = block slot 20 - pos = frame 20 - pos of the clip
+        np.testing.assert_array_equal(stack[20 - pos][ry:ry + Hc, rx:rx + Wc], clip[20 - pos][30:90, 40:160])
     # a shuffled queue (or frames of two windows) is staged instead
     mixed = q.get_queue()[::-1]
-    stack2, (rx2, ry2), _ = stack_frames(mixed, CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
-    assert made == [(21, 84, 144, 3)] and (rx2, ry2) == (12, 12)
+    mixed[3], mixed[4] = mixed[4], mixed[3]
+    stack2, (rx2, ry2), _, backwards2 = stack_frames(mixed, CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert made == [(21, 84, 144, 3)] and (rx2, ry2) == (12, 12) and not backwards2
     for pos in range(21):
-        np.testing.assert_array_equal(stack2[pos][ry2:ry2 + Hc, rx2:rx2 + Wc], clip[pos][30:90, 40:160])
+        src = {3: 4, 4: 3}.get(pos, pos)
+        np.testing.assert_array_equal(stack2[pos][ry2:ry2 + Hc, rx2:rx2 + Wc], clip[src][30:90, 40:160])
     # full frames: cropped to ROI + margin
-    stack3, (rx3, ry3), _ = stack_frames([clip[i] for i in range(20, -1, -1)], CROP, (24, 24), lambda shape: np.empty(shape, np.uint8))
-    np.testing.assert_array_equal(stack3, stack)
+    stack3, (rx3, ry3), _, backwards3 = stack_frames([clip[i] for i in range(20, -1, -1)], CROP, (24, 24), lambda shape: np.empty(shape, np.uint8))
+    np.testing.assert_array_equal(stack3, stack[::-1])
+    assert not backwards3
 
 
 @pytest.mark.gpu
