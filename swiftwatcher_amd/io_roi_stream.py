@@ -146,7 +146,7 @@ class RoiStreamReader:
     BLOCKS = 6          # a block is reused five windows later: by then few of its frames are still referenced (tracks last 1-2 windows)
     MAX_BLOCKS = 32     # the ring grows when most frames of the block in turn are still in use (a caller that reads many windows ahead)
 
-    def __init__(self, path, start=0, end=0, prefetch=True, device=0):
+    def __init__(self, path, start=0, end=0, prefetch=True, device=0, ahead=1):
         self.filepath = path
         with open(path, "rb") as fh:
             head = fh.read(len(MAGIC) + 4)
@@ -183,7 +183,8 @@ class RoiStreamReader:
         self._blocks, self._alive, self._turn = [], [], 0
         self._spare = []                     # pixel buffers of detached frames that have died since
         self._prefetch = prefetch
-        self._pending = None                 # (first frame number, n, block index, "done" event)
+        self.ahead = max(int(ahead), 1)      # windows read ahead of the caller (a caller that takes several windows per GPU call sets it)
+        self._pending = []                   # windows being read ahead, oldest first: (first frame number, n, (block, alive), "done" event)
         self._jobs = None                    # queue of the read-ahead thread (started with the first window)
 
     # ---- the reference reader's surface ----
@@ -224,9 +225,9 @@ class RoiStreamReader:
 
     def close(self):
         if getattr(self, "_fd", None) is not None:
-            if self._pending is not None:
-                self._pending[3].wait()
-                self._pending = None
+            for pend in self._pending:
+                pend[3].wait()
+            self._pending = []
             if self._jobs is not None:
                 self._jobs.put(None)
                 self._jobs = None
@@ -277,8 +278,8 @@ class RoiStreamReader:
             elif number >= self.count:
                 if k > 0 and number - 1 < self.count:
                     block[k] = block[k - 1]
-                elif self.last_read_frame is not None:
-                    block[k] = self.last_read_frame.roi
+                elif self.count > 0 and number - 1 >= self.start_frame:
+                    self._read_into(self.count - 1, block[k])          # the window starts with the re-delivered frame: the file's last one
                 else:
                     block[k] = 0
 
@@ -295,18 +296,22 @@ class RoiStreamReader:
             done.set()
 
     def _start_prefetch(self, first, n):
-        if not self._prefetch or first > self.end_frame:
-            self._pending = None
+        """Keep `ahead` windows in flight beyond the one just delivered (first = the frame number the next window starts at)."""
+        if not self._prefetch:
             return
-        if self._jobs is None:
-            import queue
-            self._jobs = queue.Queue()
-            threading.Thread(target=self._reader_loop, args=(self._jobs,), daemon=True).start()
-        block, alive = self._block(n)
-        done = threading.Event()
-        done.error = None
-        self._jobs.put((block, first, n, done))
-        self._pending = (first, n, (block, alive), done)
+        if self._pending:
+            first = self._pending[-1][0] + n
+        while len(self._pending) < self.ahead and first <= self.end_frame:
+            if self._jobs is None:
+                import queue
+                self._jobs = queue.Queue()
+                threading.Thread(target=self._reader_loop, args=(self._jobs,), daemon=True).start()
+            block, alive = self._block(n)
+            done = threading.Event()
+            done.error = None
+            self._jobs.put((block, first, n, done))
+            self._pending.append((first, n, (block, alive), done))
+            first += n
 
     def _wait(self, pend):
         pend[3].wait()
@@ -315,16 +320,16 @@ class RoiStreamReader:
 
     def get_n_frames(self, n):
         first = self.next_frame_number
-        pend = self._pending
-        if pend is not None and pend[0] == first and pend[1] == n:
+        if self._pending and self._pending[0][0] == first and self._pending[0][1] == n:
+            pend = self._pending.pop(0)
             self._wait(pend)
             block, alive = pend[2]
         else:
-            if pend is not None:
+            for pend in self._pending:           # read ahead for another position or window size: let it finish, then read here
                 self._wait(pend)
+            self._pending = []
             block, alive = self._block(n)
             self._fill(block, first, n)
-        self._pending = None
         frames, numbers, stamps = [], [], []
         for k in range(n):
             number = self.next_frame_number

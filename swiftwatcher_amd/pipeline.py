@@ -25,6 +25,8 @@ def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size
         raise ValueError("either corners or crop_region + roi_mask are needed")
     tracker = SegmentTracker(roi_mask)
     if windows_per_call > 1:
+        if hasattr(reader, "ahead"):                 # a reader that reads ahead (io_roi_stream): as far as one GPU call takes
+            reader.ahead = max(reader.ahead, windows_per_call)
         # producer thread: reads ahead and segments (GPU call and array copies release the GIL);
         # this thread: classifier and the strictly sequential tracker
         import queue as _queue
