@@ -105,7 +105,9 @@ def launch_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's JSON line and nothing else (a backend may chat on stdout: gloo prints its peer count there)
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    sys.stdout.write((lines[-1] + "\n") if lines else out.decode())
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 

@@ -14,6 +14,13 @@ a)
   rm -rf gpurun_out/r3m/prof
   head -12 gpurun_out/r3m/r3_kernel_stats_default_bench.csv
   ;;
+c)
+  python tools/prof_pipeline.py 16 1 > gpurun_out/r3m/r3_count_loop_profile.txt 2>&1
+  python tools/prof_batched.py > gpurun_out/r3m/r3_batched_loop_profile.txt 2>&1
+  SWK_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --windows 32 --no-cpu-baseline > gpurun_out/r3m/launcher_2ranks_gloo_one_gpu.json 2> gpurun_out/r3m/launcher.err
+  tail -c 900 gpurun_out/r3m/launcher_2ranks_gloo_one_gpu.json
+  python bench.py > gpurun_out/r3m/default.json 2> gpurun_out/r3m/default.err
+  ;;
 b)
   python bench.py --no-cpu-baseline --no-drop-in --size P3 --n 21 --windows 96 --steps 5 > gpurun_out/r3m/p3_n21.json 2>/dev/null
   python bench.py --no-cpu-baseline --no-drop-in --n 21 --windows 384 --steps 5 > gpurun_out/r3m/n21.json 2>/dev/null

@@ -36,7 +36,8 @@ if classify:
     crops = [s.segment_image for f in q for s in f.segments]
     sd = cref.calibrate_head(cref.random_state_dict(4), crops[:60])
     clf = SegmentClassifier.from_state_dict(sd, batch_size=2048)
-make_reader = lambda fr: ArrayReader(fr)                             # noqa: E731
+_AR = ArrayReader
+make_reader = lambda fr: _AR(fr)                                     # noqa: E731
 if len(sys.argv) > 3 and sys.argv[3] == "roi":
     import tempfile
     from swiftwatcher_amd.io_roi_stream import RoiStreamReader, write_roi_stream
@@ -47,7 +48,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "roi":
         if len(fr) not in paths:
             paths[len(fr)] = write_roi_stream(os.path.join(tmpdir, "clip%d.swkroi" % len(fr)), fr, crop_region)
         return RoiStreamReader(paths[len(fr)])
-_AR = ArrayReader
 ArrayReader = make_reader
 for _ in range(2):
     pipeline.swift_counting_algorithm(ArrayReader(frames[:4 * queue]), crop_region, roi_mask, classifier=clf, keep_stages=True)
