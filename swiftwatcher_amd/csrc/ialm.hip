@@ -220,6 +220,138 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Windows of 65 .. 128 frames: variant 1 with four waves per 64-pixel tile.  The per-pixel loops over the frames are dealt to the
+// waves (frame j or i = wave, wave + 4, ...: every sum keeps variant 1's order, so for n <= 64 the two kernels agree bit for bit --
+// the GPU test runs both), the tile's Gram is formed by 16 x 16 threads owning 8 x 8 entries each.  LDS: 2 x n8 x 65 doubles
+// (133 KB at 128 frames).  A correctness path for queues no BASELINE configuration uses (data_structures.py:120: queue_size is free).
+// ---------------------------------------------------------------------------------
+template <int MODE, bool WRITE_E>
+__global__ __launch_bounds__(256) void k_ialm_pass_wide(IalmBuffers b)
+{
+    extern __shared__ double lds[];
+    const int n = b.n, P = b.P;
+    const int n8 = (n + 7) & ~7;
+    double *sm = lds;                    // [n8][65]  M of the iteration being finished
+    double *se = lds + n8 * kLdsRow;     // [n8][65]  E of it, then M of the next iteration
+    const int w = blockIdx.y;
+    const IalmWin &st = b.win[w];
+    if (st.done) return;
+    const int tid = threadIdx.x, t = tid & 63, wave = tid >> 6;
+    const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
+    const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;
+    const double dual = st.dual_norm;
+    const int64_t wbase = (int64_t)w * n * P, ps = b.pstride;
+    const uint8_t *X = b.X + wbase;
+    double *A = b.A + (int64_t)w * b.fpad * ps, *Y = b.Y + (int64_t)w * b.fpad * ps;
+    uint8_t *S = b.S + wbase;
+    double *Eo = WRITE_E ? b.E + (int64_t)w * b.fpad * ps : nullptr;
+    const double *Bm = b.Bm + (int64_t)w * n * n;
+
+    for (int j = n + wave; j < n8; j += 4) { sm[j * kLdsRow + t] = 0.0; se[j * kLdsRow + t] = 0.0; }
+
+    const int ti = tid >> 4, tj = tid & 15;          // this thread's 8 x 8 block of the Gram matrix
+    double g[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[a][c] = 0.0;
+    double zz = 0.0;
+
+    const int ntiles = (P + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p = tile * 64 + t;
+        const bool valid = p < P;
+        const int pc = valid ? p : P - 1;
+        if (MODE != 0) {
+            for (int j = wave; j < n; j += 4) {
+                const int64_t idx = (int64_t)j * ps + pc;
+                const double x = (double)X[(int64_t)j * P + pc];
+                double a, y;
+                if (MODE == 1) { a = 0.0; y = x / dual; }                 // :272-273
+                else { a = A[idx]; y = Y[idx]; }
+                const double raw = (x - a) + inv_mu * y;                  // :282
+                const double e = shrink(raw, thr);                        // :283
+                const double m = (x - e) + inv_mu * y;                    // :284 (SVD input)
+                sm[j * kLdsRow + t] = m;
+                se[j * kLdsRow + t] = e;
+            }
+            __syncthreads();
+        }
+        for (int i = wave; i < n; i += 4) {
+            const int64_t idx = (int64_t)i * ps + pc;
+            const double x = (double)X[(int64_t)i * P + pc];
+            double a_new, y;
+            if (MODE == 0) {
+                a_new = 0.0;
+                y = x / dual;
+            } else {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j) acc += sm[j * kLdsRow + t] * Bm[j * n + i];   // :290
+                a_new = acc;
+                const double e = se[i * kLdsRow + t];
+                const double z = (x - a_new) - e;                         // :293
+                const double y_prev = MODE == 1 ? x / dual : Y[idx];
+                y = y_prev + mu * z;                                      // :294
+                if (valid) {
+                    zz += z * z;
+                    A[idx] = a_new;
+                    Y[idx] = y;
+                    S[(int64_t)i * P + pc] = sparse_u8(e);
+                    if (WRITE_E) Eo[idx] = e;
+                }
+            }
+            const double raw2 = (x - a_new) + inv_mu2 * y;
+            const double e2 = shrink(raw2, thr2);
+            const double m2 = (x - e2) + inv_mu2 * y;
+            se[i * kLdsRow + t] = valid ? m2 : 0.0;
+        }
+        __syncthreads();
+        if (8 * ti < n && 8 * tj < n) {
+            for (int q = 0; q < 64; ++q) {
+                double ra[8], rb[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) ra[a] = se[(8 * ti + a) * kLdsRow + q];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rb[c] = se[(8 * tj + c) * kLdsRow + q];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) g[a][c] += ra[a] * rb[c];
+            }
+        }
+        __syncthreads();
+    }
+    double *gp = b.gpart + ((int64_t)w * b.nblk + blockIdx.x) * n * n;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = 8 * ti + a, j = 8 * tj + c;
+            if (i < n && j < n) gp[i * n + j] = g[a][c];
+        }
+    if (MODE != 0) {
+        // variant 1 sums a pixel's z^2 over the frames in order; here a pixel's frames are dealt to four waves: per-wave sums in frame
+        // order, then the waves in order (float64: the stopping ratio moves in its 14th digit against variant 1)
+        for (int off = 32; off; off >>= 1) zz += __shfl_down(zz, off);
+        __shared__ double zw[4];
+        if (t == 0) zw[wave] = zz;
+        __syncthreads();
+        if (tid == 0) b.zzpart[(int64_t)w * b.nblk + blockIdx.x] = ((zw[0] + zw[1]) + zw[2]) + zw[3];
+    }
+}
+
+template <int MODE, bool WE>
+static void launch_wide(hipStream_t s, const IalmBuffers &b)
+{
+    const int n8 = (b.n + 7) & ~7;
+    const size_t lds = (size_t)2 * n8 * kLdsRow * sizeof(double);
+    static unsigned long long attr_mask = 0;
+    if (!ensure_dyn_lds((const void *)k_ialm_pass_wide<MODE, WE>, 2 * kMaxNWide * kLdsRow * 8, attr_mask)) return;
+    hipLaunchKernelGGL((k_ialm_pass_wide<MODE, WE>), dim3(b.nblk, b.nwin), dim3(256), lds, s, b);
+    note_launch();
+}
+
 // planes [nwin][n][P] -> reference layout [nwin][P][n]
 __global__ void k_planes_to_pn(const double *__restrict__ planes, double *__restrict__ out, int n, int P, int64_t ps, int fpad)
 {
@@ -243,7 +375,7 @@ __global__ void k_rpca_epilogue(const double *__restrict__ E, int64_t count, uin
 int ialm_pass_nblk(int variant, int n, int P, int nwin)
 {
     (void)n;
-    if (variant >= 2) {
+    if (variant >= 2 && variant != 6) {
         // 256-thread blocks, two resident per CU (LDS and registers).
         // Several rounds of blocks per CU keep the tail short when a few CUs are busy with another
         // group's eigen-solve; the cap bounds the Gram partial slabs (nblk x n^2 doubles per window).
@@ -300,6 +432,13 @@ void launch_ialm_pass_v3(hipStream_t s, const IalmBuffers &b, int mode, int k);
 
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k, int tune)
 {
+    if (variant == 6) {          // 65 .. 128 frames (also accepted below that: the tests compare it with variant 1)
+        const bool we6 = b.E != nullptr;
+        if (mode == 0) launch_wide<0, false>(s, b);
+        else if (mode == 1) { if (we6) launch_wide<1, true>(s, b); else launch_wide<1, false>(s, b); }
+        else { if (we6) launch_wide<2, true>(s, b); else launch_wide<2, false>(s, b); }
+        return;
+    }
     if (variant >= 4) { launch_ialm_pass_m(s, b, mode, k, tune, variant == 4); return; }
     if (variant == 3) { launch_ialm_pass_v3(s, b, mode, k); return; }
     if (variant == 2) { launch_ialm_pass_v2(s, b, mode); return; }

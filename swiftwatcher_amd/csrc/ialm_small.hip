@@ -134,13 +134,14 @@ __device__ __forceinline__ void gram_reduce(const IalmBuffers &b, int w, double 
 // block in place, V <- V J alongside.  Leaves W = V diag(lambda^-1/2) V^T in Wout (pitch kJac);
 // eigenvalues below 1e-13 lambda_max get weight 0.
 // ---------------------------------------------------------------------------------
-__device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double2 *cs, int *pq, double *wgt, int *flag, int *sweeps_out)
+__device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double2 *cs, int *pq, double *wgt, int *flag, int *sweeps_out,
+                               int pitch = kJac)
 {
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    for (int idx = tid; idx < n * n; idx += nthreads) { const int i = idx / n, j = idx - i * n; V[i * kJac + j] = i == j ? 1.0 : 0.0; }
+    for (int idx = tid; idx < n * n; idx += nthreads) { const int i = idx / n, j = idx - i * n; V[i * pitch + j] = i == j ? 1.0 : 0.0; }
     if ((n & 1) && tid <= n) {                 // zero row/column at the dummy index of an odd n
-        G[n * kJac + tid] = 0.0;
-        G[tid * kJac + n] = 0.0;
+        G[n * pitch + tid] = 0.0;
+        G[tid * pitch + n] = 0.0;
     }
     __syncthreads();
     const int m = n + (n & 1), half = m / 2;
@@ -154,7 +155,7 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
                 round_robin_pair(m, r, tid, p, q);
                 double c = 1.0, s = 0.0;
                 if (q < n) {
-                    const double gpq = G[p * kJac + q], gpp = G[p * kJac + p], gqq = G[q * kJac + q];
+                    const double gpq = G[p * pitch + q], gpp = G[p * pitch + p], gqq = G[q * pitch + q];
                     const double g2 = gpq * gpq, dd = fabs(gpp * gqq);
                     if (gpq != 0.0 && g2 > 1e-30 * dd) {
                         if (g2 > 1e-16 * dd) *flag = 1;
@@ -175,14 +176,14 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
                 if (ra.y == 0.0 && rb.y == 0.0) continue;
                 const int pqa = pq[ka], pqb = pq[kb];
                 const int pa = pqa & 255, qa = pqa >> 8, pb = pqb & 255, qb = pqb >> 8;
-                const double g00 = G[pa * kJac + pb], g01 = G[pa * kJac + qb];
-                const double g10 = G[qa * kJac + pb], g11 = G[qa * kJac + qb];
+                const double g00 = G[pa * pitch + pb], g01 = G[pa * pitch + qb];
+                const double g10 = G[qa * pitch + pb], g11 = G[qa * pitch + qb];
                 const double r00 = ra.x * g00 - ra.y * g10, r01 = ra.x * g01 - ra.y * g11;
                 const double r10 = ra.y * g00 + ra.x * g10, r11 = ra.y * g01 + ra.x * g11;
-                G[pa * kJac + pb] = rb.x * r00 - rb.y * r01;
-                G[pa * kJac + qb] = rb.y * r00 + rb.x * r01;
-                G[qa * kJac + pb] = rb.x * r10 - rb.y * r11;
-                G[qa * kJac + qb] = rb.y * r10 + rb.x * r11;
+                G[pa * pitch + pb] = rb.x * r00 - rb.y * r01;
+                G[pa * pitch + qb] = rb.y * r00 + rb.x * r01;
+                G[qa * pitch + pb] = rb.x * r10 - rb.y * r11;
+                G[qa * pitch + qb] = rb.y * r10 + rb.x * r11;
             }
             for (int idx = tid; idx < n * half; idx += nthreads) {
                 const int i = idx / half, kk = idx - i * half;
@@ -190,9 +191,9 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
                 if (rk.y == 0.0) continue;
                 const int pqk = pq[kk];
                 const int p = pqk & 255, q = pqk >> 8;
-                const double vp = V[i * kJac + p], vq = V[i * kJac + q];
-                V[i * kJac + p] = rk.x * vp - rk.y * vq;
-                V[i * kJac + q] = rk.y * vp + rk.x * vq;
+                const double vp = V[i * pitch + p], vq = V[i * pitch + q];
+                V[i * pitch + p] = rk.x * vp - rk.y * vq;
+                V[i * pitch + q] = rk.y * vp + rk.x * vq;
             }
             __syncthreads();
         }
@@ -204,17 +205,20 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
         if (!big) break;
     }
     if (tid < 64) {
-        double lam = tid < n ? G[tid * kJac + tid] : 0.0;
-        double lmax = lam;
+        // (n <= 64: one value per lane; the wide kernel's 65 .. 128 frames: two)
+        double lam = tid < n ? G[tid * pitch + tid] : 0.0;
+        double lam2 = tid + 64 < n ? G[(tid + 64) * pitch + tid + 64] : 0.0;
+        double lmax = fmax(lam, lam2);
         for (int off = 32; off; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
         if (tid < n) wgt[tid] = lam > 1e-13 * lmax ? 1.0 / sqrt(lam) : 0.0;
+        if (tid + 64 < n) wgt[tid + 64] = lam2 > 1e-13 * lmax ? 1.0 / sqrt(lam2) : 0.0;
     }
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += nthreads) {
         const int i = idx / n, j = idx - i * n;
         double acc = 0.0;
-        for (int kk = 0; kk < n; ++kk) acc += V[i * kJac + kk] * wgt[kk] * V[j * kJac + kk];
-        Wout[i * kJac + j] = acc;
+        for (int kk = 0; kk < n; ++kk) acc += V[i * pitch + kk] * wgt[kk] * V[j * pitch + kk];
+        Wout[i * pitch + j] = acc;
     }
     __syncthreads();
     *sweeps_out = sweeps;
@@ -441,6 +445,43 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(IalmBuffers b)
         for (int g = 0; g < 16; ++g) acc += part[g][lane];
         gp[idx] = acc;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Windows of 65 .. 128 frames (FrameQueue(queue_size) is unbounded in the reference, data_structures.py:120; no BASELINE configuration
+// uses such a queue).  The three n x n matrices of the eigen-solve do not fit the LDS next to each other, so they live in global memory
+// (131 KB each at n = 128: L2 resident) and the solver is the cyclic Jacobi iteration alone -- the same code, another pitch.  A
+// correctness path: milliseconds per IALM iteration, one workgroup per window.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSmallThreads) void k_ialm_small_wide(IalmBuffers b, int k, double lmbda, double tol, int maxiter, double *work)
+{
+    __shared__ double red[kSmallThreads];
+    __shared__ double2 cs[kMaxNWide / 2];
+    __shared__ double wgt[kMaxNWide];
+    __shared__ int pq[kMaxNWide / 2];
+    __shared__ int flags[2];
+    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nthreads = blockDim.x, pitch = n + 2;
+    IalmScal cur;
+    if (!small_prologue(b, w, k, lmbda, tol, maxiter, red, cur)) return;
+    double *G = work + (size_t)w * 3 * pitch * pitch, *V = G + (size_t)pitch * pitch, *Wm = V + (size_t)pitch * pitch;
+    gram_reduce(b, w, G, pitch, k);
+    __syncthreads();
+    int sweeps = 0;
+    jacobi_invsqrt(G, V, Wm, n, cs, pq, wgt, flags, &sweeps, pitch);
+    double *Bm = b.Bm + (int64_t)w * n * n;
+    for (int idx = tid; idx < n * n; idx += nthreads) {
+        const int i = idx / n, j = idx - i * n;
+        Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * Wm[i * pitch + j];
+    }
+    if (tid == 0) b.win[w].sweeps = 100 + sweeps;
+}
+
+size_t ialm_small_wide_doubles(int n) { return (size_t)3 * (n + 2) * (n + 2); }
+
+void launch_ialm_small_wide(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, double *work)
+{
+    hipLaunchKernelGGL(k_ialm_small_wide, dim3(b.nwin), dim3(kSmallThreads), 0, s, b, k, lmbda, tol, maxiter, work);
+    note_launch();
 }
 
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)

@@ -21,7 +21,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_SALT, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_SALT, SL_WIDE, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -263,15 +263,17 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
              bool want_A, bool want_E, uint8_t *dS, int32_t *h_iters /*host, optional*/, int32_t *d_iters /*device, optional*/,
              bool speculate = true, int force_variant = 0)
 {
-    if (n < 1 || n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..64");
+    if (n < 1 || n > kMaxNWide) return fail(ctx, SWK_ERR_ARG, "frames per window must be in 1..128");
+    const bool wide = n > kMaxN;          // 65 .. 128 frames: the plain f64 kernels (A/Y state, Jacobi in global memory)
     IalmBuffers b{};
     b.X = dX; b.S = dS; b.nwin = nwin; b.n = n; b.P = P;
     // auto: the M-state pass (k-step-templated, 21 B/element) unless the caller wants the f64 low-rank / sparse matrices,
     // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = force_variant ? force_variant : ctx->ialm_variant;
     if (variant == 0) variant = 4;
-    if (variant >= 3 && (want_A || want_E)) variant = 2;
-    const bool mstate = variant >= 3;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
+    if (variant >= 3 && variant != 6 && (want_A || want_E)) variant = 2;
+    if (wide) variant = 6;
+    const bool mstate = variant >= 3 && variant != 6;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
     // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
     // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
     // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
@@ -281,7 +283,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
     b.nred = b.nblk > 4 ? 1 : b.nblk;       // several slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
-    b.fpad = variant >= 4 ? ialm_mstate_fpad(n) : (n + 15) & ~15;
+    b.fpad = (variant >= 4 && variant != 6) ? ialm_mstate_fpad(n) : (n + 15) & ~15;
     ctx->pstride = b.pstride;
     ctx->fpad = b.fpad;
     if ((int64_t)b.fpad * b.pstride >= (1ll << 28)) return fail(ctx, SWK_ERR_ARG, "window too large: frames x ROI pixels must stay below 2^28");
@@ -307,6 +309,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_ZZPART, (size_t)nwin * b.nblk * 8, b.zzpart);
     NEED(ctx, SL_WIN, (size_t)nwin * sizeof(IalmWin), b.win);
     NEED(ctx, SL_ACTIVE, 16 * sizeof(int), b.active);
+    double *wide_work = nullptr;
+    if (variant == 6) NEED(ctx, SL_WIDE, (size_t)nwin * ialm_small_wide_doubles(n) * sizeof(double), wide_work);
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(b.win, 0, (size_t)nwin * sizeof(IalmWin), s));
     HIPCHK(ctx, hipMemsetAsync(b.active, 0, 16 * sizeof(int), s));
@@ -376,7 +380,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         }
         { Timed t(ctx, SWK_K_IALM_SMALL, gs0);
           if (grp[g].b.nblk > 4) launch_gram_reduce(gs0, grp[g].b);
-          launch_ialm_small(gs0, grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
+          if (variant == 6) launch_ialm_small_wide(gs0, grp[g].b, 0, lmbda, tol, maxiter, wide_work + (size_t)grp[g].w0 * ialm_small_wide_doubles(n));
+          else launch_ialm_small(gs0, grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
         if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs0));
     }
     for (int k = 1; k <= maxiter + 2; ++k) {
@@ -402,7 +407,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
             }
             { Timed t(ctx, SWK_K_IALM_SMALL, gs);
               if (gr.b.nblk > 4) launch_gram_reduce(gs, gr.b);
-              launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
+              if (variant == 6) launch_ialm_small_wide(gs, gr.b, k, lmbda, tol, maxiter, wide_work + (size_t)gr.w0 * ialm_small_wide_doubles(n));
+              else launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
             if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
             if (k >= check_from) {
                 HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));
@@ -630,7 +636,7 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters)
 }
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 5) return SWK_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 6) return SWK_ERR_ARG;
     ctx->ialm_variant = variant;
     return SWK_OK;
 }
@@ -773,7 +779,7 @@ int32_t swk_batch_run(swk_ctx *ctx, const swk_input *in, const swk_params *p, sw
     if (!in || !p || !out || !in->frames) return fail(ctx, SWK_ERR_ARG, "null argument");
     if (in->nwin < 1 || in->n < 1 || in->Hc < 1 || in->Wc < 1) return fail(ctx, SWK_ERR_ARG, "empty batch");
     if (in->channels != 1 && in->channels != 3) return fail(ctx, SWK_ERR_ARG, "channels must be 1 or 3");
-    if (in->n > kMaxN) return fail(ctx, SWK_ERR_ARG, "frames per window must be <= 64");
+    if (in->n > kMaxNWide) return fail(ctx, SWK_ERR_ARG, "frames per window must be <= 128");
     if (p->open_kh != 3 || p->open_kw != 3) return fail(ctx, SWK_ERR_ARG, "only the (3,3) opening window is implemented");
     if (p->connectivity != 4 && p->connectivity != 8) return fail(ctx, SWK_ERR_ARG, "connectivity must be 4 or 8");
     if (p->bil_d / 2 != 3) return fail(ctx, SWK_ERR_ARG, "the fused filter kernel implements bilateral d=7 (radius 3) only");

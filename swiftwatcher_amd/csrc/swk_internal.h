@@ -7,7 +7,8 @@
 
 namespace swk {
 
-constexpr int kMaxN = 64;          // frames per window supported by the IALM kernels
+constexpr int kMaxN = 64;          // frames per window supported by the matrix-core IALM kernels
+constexpr int kMaxNWide = 128;     // ... and by the plain f64 kernels that take over above that (k_ialm_pass_wide, k_ialm_small_wide)
 
 // Kernels that take more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute
 // belongs to the (kernel, device) pair: `mask` (one static per kernel instantiation) keeps a bit per device it has been
@@ -109,6 +110,9 @@ int  ialm_mstate_fpad(int n);
 void launch_select_sparse(hipStream_t s, const IalmBuffers &b);
 // method: 0 = Newton-Schulz on the f64 matrix cores (Jacobi only as fallback), 1 = cyclic Jacobi
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method);
+// windows of 65 .. 128 frames: cyclic Jacobi with its matrices in global memory (work: 3 (n + 2)^2 doubles per window)
+void launch_ialm_small_wide(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, double *work);
+size_t ialm_small_wide_doubles(int n);
 // sums the nblk Gram partial slabs of every live window into slab 0, in fixed order, chip-wide
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b);
 // ialm_gram8.hip: exact X^T X, sum of squares and max of every window on the i8 matrix cores

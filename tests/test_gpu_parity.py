@@ -745,3 +745,57 @@ def test_roi_at_the_frame_corner_and_gray_frames(orc):
     for pos in range(n):
         np.testing.assert_array_equal(q[pos].processed_frames["cc_labeling"], ref["labels"][pos])
         assert all(not hasattr(s, "_batch") for s in q[pos].segments)
+
+
+def test_windows_of_more_than_64_frames(orc):
+    """FrameQueue(queue_size) is free in the reference (data_structures.py:120).  Up to 64 frames the matrix-core kernels run; 65 .. 128
+    frames take the plain float64 kernels (k_ialm_pass_wide: variant 1 with four waves per tile; k_ialm_small_wide: cyclic Jacobi with
+    its matrices in global memory).  (a) below 65 frames the wide kernels agree with variant 1 + Jacobi: same iteration count, same u8
+    image, A and E to the last bits (only the order of the stopping norm's sum differs); (b) windows of 65, 96 and 128 frames against
+    the oracle: every stage image, the region records, A and E within 1e-5; (c) the drop-in: FrameQueue(queue_size=96)."""
+    from swiftwatcher_amd import _lib, synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    wide, v1 = _lib.Context(0), _lib.Context(0)
+    wide.set_ialm_variant(6)
+    v1.set_ialm_variant(1)
+    v1.set_eig_method(1)
+    for n, Hc, Wc in ((21, 40, 60), (64, 33, 47)):
+        roi = synthetic.roi_window(3000 + n, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
+        a, b = wide.batch_run(roi, 1, n, want_A=True, want_E=True), v1.batch_run(roi, 1, n, want_A=True, want_E=True)
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        for key in ("rpca", "labels"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        np.testing.assert_allclose(a["A"], b["A"], atol=1e-11, rtol=0)
+        np.testing.assert_allclose(a["E"], b["E"], atol=1e-11, rtol=0)
+    v1.close()
+    wide.close()
+    ctx = _lib.Context(0)                                  # default context: n > 64 selects the wide kernels by itself
+    for n, Hc, Wc in ((65, 40, 56), (96, 48, 64), (128, 37, 51)):
+        roi = synthetic.roi_window(3100 + n, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
+        res = ctx.batch_run(roi, 1, n, want_A=True, want_E=True)
+        ref = orc.window(roi)
+        gray = ref["gray"].reshape(n, -1).T
+        A0, E0, k0 = orc.ialm(gray, return_iters=True)
+        assert int(res["iters"][0]) == k0, n
+        np.testing.assert_allclose(res["A"][0], A0, atol=ATOL_AE, rtol=0)
+        np.testing.assert_allclose(res["E"][0], E0, atol=ATOL_AE, rtol=0)
+        for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+            np.testing.assert_array_equal(res[key], ref[key], err_msg="%s n=%d" % (key, n))
+        for i in range(n):
+            got = [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"])) for s in res["segs"][i, :res["nseg"][i]]]
+            assert got == [(s["label"],) + s["bbox"] + (s["area"],) for s in ref["segments"][i]]
+    with pytest.raises(_lib.SwkError):
+        ctx.batch_run(np.zeros((129, 8, 8), np.uint8), 1, 129)
+    ctx.close()
+    crop_region = [(20, 10), (20 + 64, 10 + 48)]
+    n = 96
+    frames = synthetic.full_frames(3200, n, crop_region, frame_hw=(70, 110), birds=3, bird_len=(8, 12), bird_wid=(3, 5))
+    q = FrameQueue(queue_size=n)
+    q.push_list_of_frames([frames[i] for i in range(n - 1, -1, -1)], list(range(n)), ["t"] * n)
+    q.preprocess_queue(crop_region, None)
+    q.segment_queue((24, 24), crop_region)
+    ref = orc.window(np.ascontiguousarray(frames[:, 10:58, 20:84]))
+    for pos in (0, 50, 95):
+        np.testing.assert_array_equal(q[pos].processed_frames["cc_labeling"], ref["labels"][pos])
+        assert [(s.label, s.bbox, s.centroid) for s in q[pos].segments] == [(s["label"], s["bbox"], s["centroid"]) for s in ref["segments"][pos]]
+    assert sum(len(f.segments) for f in q) >= 20
