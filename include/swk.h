@@ -101,7 +101,8 @@ typedef struct swk_input {
     int32_t channels;       /* 3 = BGR (convert_grayscale runs), 1 = already gray (passes
                                through, image_filtering.py:193-194) */
     int32_t nwin;           /* windows in this batch */
-    int32_t n;              /* frames per window = FrameQueue queue_size (21 default) */
+    int32_t n;              /* frames per window = FrameQueue queue_size (21 default); up to 128 (65 .. 128 run on plain
+                               float64 kernels: correct, not fast) */
     int32_t Hc, Wc;         /* ROI rows, cols */
     int32_t x0, y0;         /* ROI origin inside each frame */
     int64_t frame_stride;   /* bytes */
@@ -338,7 +339,8 @@ int32_t swk_prof_reset(swk_ctx *ctx);
 int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *launches);
 /* Total IALM pass launches x windows still active, i.e. window-iterations streamed. */
 int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
-/* Select the IALM pass kernel: 0 = auto (4, or 2 when A / E are requested), 1 = LDS/VALU kernel,
+/* Select the IALM pass kernel: 0 = auto (4, or 2 when A / E are requested, 6 above 64 frames), 6 = the plain float64 kernels of long
+ * windows (accepted for any n: the tests compare them with 1), 1 = LDS/VALU kernel,
  * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per
  * element and iteration; produces the sparse u8 image and the iteration count, not A / E), instantiated per 16-frame
  * block; 4 = the same pass instantiated per 4-frame k-step with a software-pipelined tile loop, 5 = 4 without the pipeline.
