@@ -190,6 +190,20 @@ class Frame:
                          for rp, seg in zip(regionprops_list, segment_images)]
 
 
+class Presegmented:
+    """One window that a reader segmented ahead of the counting loop (io_frames.PresegmentingReader): the frames as get_n_frames handed
+    them out (oldest first) and, per frame, the Segment objects segment_queue would have made.  Registered under the oldest frame's
+    identity; FrameQueue.segment_queue takes it when its queue holds exactly these frames and was asked for the same regions."""
+    __slots__ = ("frames", "segments", "crop_region", "min_seg_size", "params", "iters", "device")
+
+    def __init__(self, frames, segments, crop_region, min_seg_size, params, iters, device):
+        self.frames, self.segments, self.crop_region = frames, segments, [tuple(crop_region[0]), tuple(crop_region[1])]
+        self.min_seg_size, self.params, self.iters, self.device = tuple(min_seg_size), params, iters, device
+
+
+PRESEGMENTED = {}          # id(oldest frame of the window) -> Presegmented
+
+
 class WindowBatch:
     """What one segment_queue call left on the device for the classifier: the window's frames and region records, held by
     the library context until its next batch.  Segment k of the batch (frames in queue order, ascending label) carries
@@ -294,6 +308,27 @@ class FrameQueue(deque):
             slot.processed_frames["crop"] = (lambda f=frame: img.crop_frame(f, crop_region))
             slot.processed_frames["grayscale"] = (lambda f=frame: img.convert_grayscale(img.crop_frame(f, crop_region)))
 
+    def _take_presegmented(self, min_seg_size, crop_region):
+        """The window a PresegmentingReader segmented ahead, if the queue holds exactly its frames and the same regions are asked for."""
+        n = len(self)
+        pre = PRESEGMENTED.get(id(self[-1].frame))
+        if pre is None or len(pre.frames) != n or any(pre.frames[k] is not self[n - 1 - k].frame for k in range(n)):
+            return False
+        if (pre.crop_region != [tuple(crop_region[0]), tuple(crop_region[1])] or pre.min_seg_size != tuple(min_seg_size)
+                or pre.params is not self.params or pre.device != self.device):
+            return False
+        del PRESEGMENTED[id(self[-1].frame)]
+        for k in range(n):
+            self[n - 1 - k].segments = pre.segments[k]
+        self.last_iters = pre.iters
+        self._last_batch = None
+        if self.keep_stages:
+            read = _stages_on_request(self.get_queue(), crop_region, tuple(min_seg_size), self.params, self.device)
+            for key, name in STAGE_KEYS.items():
+                for i, slot in enumerate(self):
+                    slot.processed_frames[name] = (lambda k=key, i=i: read(k, i))
+        return True
+
     def _stage_window(self, min_seg_size, crop_region):
         """The window's ROI crops plus a margin of half the minimum segment size (clipped to the frame), stacked in
         page-locked memory: (staging array (n, Hm, Wm, 3), (x, y) of the ROI inside it, ROI (Hc, Wc))."""
@@ -310,6 +345,8 @@ class FrameQueue(deque):
         segment crops, one swk_batch_run for the whole window."""
         if "crop" not in self[0].processed_frames:
             raise RuntimeError("preprocess_queue must run before segment_queue")
+        if PRESEGMENTED and self._take_presegmented(min_seg_size, crop_region):
+            return
         stack, (rx, ry), (Hc, Wc), backwards = self._stage_window(min_seg_size, crop_region)
         n = stack.shape[0]
         ctx = _lib.default_context(self.device)
@@ -337,6 +374,22 @@ class FrameQueue(deque):
                 for i, slot in enumerate(self):
                     slot.processed_frames[name] = (lambda k=key, i=i, p=planes: p.read(k, i))
         window_segments(res["segs"], nseg, list(self), tuple(min_seg_size), crop_region, batch)
+
+
+def _stages_on_request(frames, crop_region, min_seg_size, params, device):
+    """processed_frames values of a window that was segmented ahead without stage images: the first read runs the window once more
+    with the images switched on (a debugging read, not part of the counting loop)."""
+    state = {}
+
+    def read(key, pos):
+        if "planes" not in state:
+            ctx = _lib.default_context(device)
+            stack, (rx, ry), (Hc, Wc), backwards = stack_frames(frames, crop_region, min_seg_size, ctx.staging)
+            res = ctx.batch_run(stack, 1, len(frames), crop=(rx, ry, Wc, Hc), params=params, stages=tuple(STAGE_KEYS), device_stages=True,
+                                reverse_frames=backwards)
+            state["planes"] = res["planes"]
+        return state["planes"].read(key, pos)
+    return read
 
 
 def stack_frames(frames, crop_region, min_seg_size, buffer):
@@ -374,13 +427,15 @@ def _margin_rect(frame_shape, crop_region, min_seg_size):
     return (max(y0 - my, 0), min(y1 + my, Hf), max(x0 - mx, 0), min(x1 + mx, Wf)), (x0, y0, x1, y1)
 
 
-def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, params=None, classifier=None):
+def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, params=None, classifier=None, owner=None, info=None):
     """Several FrameQueue-fuls in ONE library call.  windows: list of (frames, frame_numbers, timestamps) triples as
     FrameReader.get_n_frames returns them (oldest frame first), all of the same length n.  Returns one list of Frame
     objects per window in POP order (oldest first, the order __main__.py:81-92 consumes them), segments attached
     exactly as preprocess_queue + segment_queue would have (data_structures.py:171-217).  Windows are independent in
     the reference too (the queue is emptied between them), so batching changes nothing but the launch count.
-    classifier: its scoring of the batch's segments is started on the GPU before the Python objects are made."""
+    classifier: its scoring of the batch's segments is started on the GPU before the Python objects are made.  owner: an object whose
+    _classifier_hint the batch sets when a classifier asks for its scores (a reader that segments ahead).  info: a dict that receives
+    'iters' (IALM iterations per window)."""
     if not windows:
         return []
     n = len(windows[0][0])
@@ -395,9 +450,11 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     nseg = res["nseg"]
     if np.any(nseg > res["segs"].shape[1]):
         raise _lib.SwkError("more regions in a frame than seg_cap")
-    batch = WindowBatch(ctx, ctx.generation, int(nseg.sum()), min_seg_size) if stack.ndim == 4 else None
+    batch = WindowBatch(ctx, ctx.generation, int(nseg.sum()), min_seg_size, queue=owner) if stack.ndim == 4 else None
     if batch is not None and classifier is not None:
         batch.launch(classifier)
+    if info is not None:
+        info["iters"] = [int(v) for v in res["iters"]]
     slots = [None] * (len(windows) * n)
     out = []
     for w, (frames, numbers, stamps) in enumerate(windows):

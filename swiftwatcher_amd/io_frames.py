@@ -61,6 +61,122 @@ class ArrayReader:
         return frames, numbers, stamps
 
 
+class PresegmentingReader:
+    """A frame reader that segments ahead of the counting loop.  The reference's loop (__main__.py:71-92) is strictly serial -- read a
+    queue-ful, segment it, classify and track its frames, read the next -- so its GPU work per window is a chain of latencies (§6 of
+    DESIGN.md: 2.4 ms for 21 frames with the classifier on, whatever the host does).  A reader knows which frames come next: this one
+    wraps any reader with the FrameReader surface (ArrayReader, RawFileReader, io_roi_stream.RoiStreamReader), reads `windows` queue-fuls
+    ahead in a background thread and segments them in ONE library call (data_structures.segment_windows: the same call the loop's
+    windows_per_call mode makes), and starts the classifier on the batch once a classifier has asked for scores.  get_n_frames hands
+    out the same frames, numbers and timestamps as the wrapped reader; FrameQueue.segment_queue recognises the window by its frames
+    and attaches the prepared segments instead of calling the GPU.  The loop itself stays the reference's, call by call; results are
+    identical (windows are independent).  Needs to know what segment_queue will be asked: crop_region, min_seg_size, queue_size (a ROI
+    stream carries the first two in its header).  The stage images of such a window are produced only if somebody reads them."""
+
+    def __init__(self, reader, crop_region=None, queue_size=21, windows=8, min_seg_size=None, device=0, params=None):
+        import collections
+        self.reader = reader
+        self.crop_region = crop_region if crop_region is not None else reader.crop_region
+        self.min_seg_size = tuple(min_seg_size if min_seg_size is not None else getattr(reader, "min_seg_size", (24, 24)))
+        self.queue_size, self.windows, self.device, self.params = int(queue_size), max(int(windows), 1), device, params
+        if hasattr(reader, "ahead"):
+            reader.ahead = max(reader.ahead, self.windows)
+        self._ready = collections.deque()            # windows segmented and not yet handed out: (frames, numbers, stamps, counters)
+        self._job = None                             # the batch being read and segmented: (thread event with .result / .error)
+        self._classifier_hint = None                 # set by the batch whose scores a classifier asked for (data_structures.WindowBatch)
+        self._delivered = 0
+        self._exhausted = False
+        self._sync_counters()
+
+    # the wrapped reader runs ahead: the counters the caller sees are those of the windows handed out
+    def _sync_counters(self, snap=None):
+        r = self.reader
+        snap = snap or (r.next_frame_number, r.frames_read, r.read_errors, r.last_read_frame, getattr(r, "frame_shape", None))
+        self.next_frame_number, self.frames_read, self.read_errors, self.last_read_frame, self.frame_shape = snap
+
+    def __getattr__(self, name):                     # fps, total_frames, start_frame, end_frame, filepath, read_frame, get_frame, ...
+        return getattr(self.reader, name)
+
+    def _work(self, done):
+        import threading  # noqa: F401
+        from . import data_structures as ds
+        try:
+            r = self.reader
+            triples, snaps = [], []
+            for _ in range(self.windows):
+                if r.next_frame_number > r.end_frame:            # only null frames from here on: the loop will have stopped
+                    self._exhausted = True
+                    break
+                triples.append(r.get_n_frames(self.queue_size))
+                snaps.append((r.next_frame_number, r.frames_read, r.read_errors, r.last_read_frame, getattr(r, "frame_shape", None)))
+            out = []
+            if triples:
+                hint = self._classifier_hint() if self._classifier_hint is not None else None
+                info = {}
+                popped = ds.segment_windows(triples, self.crop_region, self.min_seg_size, device=self.device, params=self.params,
+                                            classifier=hint, owner=self, info=info)
+                for (frames, numbers, stamps), snap, frs, iters in zip(triples, snaps, popped, info["iters"]):
+                    ds.PRESEGMENTED[id(frames[0])] = ds.Presegmented(list(frames), [f.segments for f in frs], self.crop_region,
+                                                                       self.min_seg_size, self.params, iters, self.device)
+                    out.append((frames, numbers, stamps, snap))
+            done.result = out
+        except BaseException as exc:                  # surfaces in get_n_frames
+            done.error = exc
+        done.set()
+
+    def _start(self):
+        import threading
+        done = threading.Event()
+        done.result, done.error = None, None
+        threading.Thread(target=self._work, args=(done,), daemon=True).start()
+        self._job = done
+
+    def _collect(self):
+        done, self._job = self._job, None
+        done.wait()
+        if done.error is not None:
+            raise done.error
+        self._ready.extend(done.result)
+
+    def get_n_frames(self, n):
+        if n != self.queue_size or (self._exhausted and not self._ready and self._job is None):
+            if self._job is not None:
+                self._collect()
+            if not self._ready:                       # another window size, or past the end: the wrapped reader as it is
+                out = self.reader.get_n_frames(n)
+                self._sync_counters()
+                return out
+        if not self._ready:
+            if self._job is None:
+                self._start()
+            self._collect()
+            if not self._ready:
+                out = self.reader.get_n_frames(n)
+                self._sync_counters()
+                return out
+        frames, numbers, stamps, snap = self._ready.popleft()
+        self._sync_counters(snap)
+        self._delivered += 1
+        # the next batch is started from the second window on (by then a classifier, if there is one, has asked for the first batch's
+        # scores: they are computed before the context moves on, and the next batch's are started with its segmentation)
+        if self._job is None and not self._exhausted and self._delivered >= 2 and len(self._ready) <= self.windows - 2:
+            self._start()
+        return frames, numbers, stamps
+
+    def close(self):
+        from . import data_structures as ds
+        if self._job is not None:
+            try:
+                self._collect()
+            except BaseException:
+                pass
+        for frames, _, _, _ in self._ready:
+            ds.PRESEGMENTED.pop(id(frames[0]), None)
+        self._ready.clear()
+        if hasattr(self.reader, "close"):
+            self.reader.close()
+
+
 class RawFileReader(ArrayReader):
     """ArrayReader over a file of decoded frames that is memory-mapped instead of loaded (SURVEY section 8f rank 2:
     "pre-extracted streams"; the image has no video codec): either a .npy array of shape (frames, H, W, 3) uint8 or a

@@ -152,3 +152,86 @@ def test_counting_loop_over_a_roi_stream_equals_the_full_frame_run(tmp_path):
     events_c = pipeline.swift_counting_algorithm(RoiStreamReader(path), corners=corners)
     count_d, events_d = pipeline.count_swifts(list(clip), corners=corners)
     assert event_signature(events_c) == event_signature(events_d)
+
+
+@pytest.mark.gpu
+def test_presegmenting_reader_leaves_the_loop_and_its_results_unchanged(tmp_path):
+    """io_frames.PresegmentingReader: the reference's loop, call by call, over a reader that segments `windows` queue-fuls ahead in
+    one GPU call.  Frames, numbers, timestamps and the reader's counters at every get_n_frames equal the wrapped reader's; events,
+    count and segment images equal the plain run's -- for frames in memory and for a ROI stream, with and without the classifier
+    (whose scoring is started with each batch's segmentation once it has been asked once); a stage image read afterwards is the
+    right one; a queue that holds other frames, or asks for other regions, is segmented the ordinary way."""
+    from swiftwatcher_amd import synthetic, pipeline, _lib
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd import data_structures as ds
+    from swiftwatcher_amd.io_frames import PresegmentingReader
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref
+    from oracle import reference_path as orc
+    from helpers import event_signature
+    corners = [(250, 200), (420, 201)]
+    crop_region = img.generate_crop_region(corners)
+    (x0, y0), (x1, y1) = crop_region
+    total = 21 * 7 + 9
+    clip = synthetic.full_frames(93, total, crop_region, frame_hw=(360, 640), birds=8, bird_len=(10, 16), bird_wid=(5, 8))[::-1].copy()
+    frames = list(clip)
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), frames, crop_region)
+    roi_mask = np.zeros((y1 - y0, x1 - x0), np.uint8)
+    roi_mask[(y1 - y0) // 2:, 20:-20] = 255
+    # the reader's surface: same windows, same counters
+    a, b = ArrayReader(frames), PresegmentingReader(ArrayReader(frames), crop_region, windows=3)
+    for _ in range(total // 21 + 1):
+        fa, na, ta = a.get_n_frames(21)
+        fb, nb, tb = b.get_n_frames(21)
+        assert na == nb and ta == tb and all(x is y or (nx < 0 and not y.any()) for x, y, nx in zip(fa, fb, na))
+        assert (a.next_frame_number, a.frames_read, a.read_errors) == (b.next_frame_number, b.frames_read, b.read_errors)
+    b.close()
+    assert not ds.PRESEGMENTED
+    q = ds.FrameQueue()
+    q.push_list_of_frames(frames[:21], list(range(21)), ["t"] * 21)
+    q.preprocess_queue(crop_region, None)
+    q.segment_queue((24, 24), crop_region)
+    crops = [s.segment_image for f in q for s in f.segments]
+    sd = classifier_ref.calibrate_head(classifier_ref.random_state_dict(9), crops)
+    clf = SegmentClassifier.from_state_dict(sd)
+    ctx = _lib.default_context(0)
+    for kw in (dict(), dict(classifier=clf)):
+        count_a, events_a = pipeline.count_swifts(frames, crop_region, roi_mask, **kw)
+        for make in (lambda: PresegmentingReader(ArrayReader(frames), crop_region, windows=3),
+                     lambda: PresegmentingReader(RoiStreamReader(path), windows=4)):
+            reader = make()
+            gen0 = ctx.generation
+            events_b = pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, **kw)
+            assert event_signature(events_b) == event_signature(events_a), kw
+            assert ec.count_swifts(events_b) == count_a
+            assert ctx.generation - gen0 <= 3                      # 8 windows in 2-3 library calls, not 8
+            for ea, eb in zip(events_a, events_b):
+                for sa, sb in zip(ea, eb):
+                    np.testing.assert_array_equal(sa.segment_image, sb.segment_image)
+            assert (reader.frames_read, reader.read_errors) == (total, 1) and not ds.PRESEGMENTED
+            reader.close()
+    assert len(events_a) >= 1
+    # stage images of a window that was segmented ahead: produced when read
+    reader = PresegmentingReader(ArrayReader(frames), crop_region, windows=2)
+    q = ds.FrameQueue()
+    fr, nu, ts = reader.get_n_frames(21)
+    q.push_list_of_frames(fr, nu, ts)
+    q.preprocess_queue(crop_region, None)
+    gen0 = ctx.generation
+    q.segment_queue((24, 24), crop_region)
+    assert ctx.generation == gen0                                   # taken from the reader's batch: no GPU call
+    ref = orc.window(np.ascontiguousarray(np.stack([f[y0:y1, x0:x1] for f in fr][::-1])))
+    np.testing.assert_array_equal(q[3].processed_frames["cc_labeling"], ref["labels"][3])
+    assert [(s.label, s.bbox, s.centroid) for s in q[3].segments] == [(s["label"], s["bbox"], s["centroid"]) for s in ref["segments"][3]]
+    # other regions asked for than the reader prepared: the ordinary path, same answer as a plain queue
+    fr, nu, ts = reader.get_n_frames(21)
+    other = [(x0 + 2, y0), (x1, y1)]
+    q2 = ds.FrameQueue()
+    q2.push_list_of_frames(fr, nu, ts)
+    q2.preprocess_queue(other, None)
+    gen0 = ctx.generation
+    q2.segment_queue((24, 24), other)
+    assert ctx.generation == gen0 + 1
+    reader.close()
+    assert not ds.PRESEGMENTED
