@@ -571,8 +571,8 @@ def test_odd_sizes_and_gray_input(ctx, orc):
 def test_error_paths(ctx):
     from swiftwatcher_amd import _lib
     rng = np.random.default_rng(0)
-    with pytest.raises(_lib.SwkError):          # more than 64 frames per window
-        ctx.batch_run(rng.integers(0, 255, size=(65, 16, 16), dtype=np.uint8), 1, 65)
+    with pytest.raises(_lib.SwkError):          # more than 128 frames per window
+        ctx.batch_run(rng.integers(0, 255, size=(129, 16, 16), dtype=np.uint8), 1, 129)
     with pytest.raises(_lib.SwkError):          # only the (3, 3) opening exists
         ctx.batch_run(rng.integers(0, 255, size=(4, 16, 16), dtype=np.uint8), 1, 4, params=_lib.default_params(open_kh=5))
     with pytest.raises(_lib.SwkError):
