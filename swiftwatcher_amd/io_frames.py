@@ -85,6 +85,7 @@ class PresegmentingReader:
         self._job = None                             # the batch being read and segmented: (thread event with .result / .error)
         self._classifier_hint = None                 # set by the batch whose scores a classifier asked for (data_structures.WindowBatch)
         self._delivered = 0
+        self._handed = collections.deque()           # keys of the windows handed out last (their entries go when the caller has moved on)
         self._exhausted = False
         self._sync_counters()
 
@@ -157,6 +158,10 @@ class PresegmentingReader:
         frames, numbers, stamps, snap = self._ready.popleft()
         self._sync_counters(snap)
         self._delivered += 1
+        from . import data_structures as ds
+        self._handed.append(id(frames[0]))
+        while len(self._handed) > 2:                  # a window nobody segmented: its prepared segments are dropped
+            ds.PRESEGMENTED.pop(self._handed.popleft(), None)
         # the next batch is started from the second window on (by then a classifier, if there is one, has asked for the first batch's
         # scores: they are computed before the context moves on, and the next batch's are started with its segmentation)
         if self._job is None and not self._exhausted and self._delivered >= 2 and len(self._ready) <= self.windows - 2:
@@ -173,6 +178,8 @@ class PresegmentingReader:
         for frames, _, _, _ in self._ready:
             ds.PRESEGMENTED.pop(id(frames[0]), None)
         self._ready.clear()
+        while self._handed:
+            ds.PRESEGMENTED.pop(self._handed.popleft(), None)
         if hasattr(self.reader, "close"):
             self.reader.close()
 
