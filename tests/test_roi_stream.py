@@ -230,8 +230,16 @@ def test_presegmenting_reader_leaves_the_loop_and_its_results_unchanged(tmp_path
     q2 = ds.FrameQueue()
     q2.push_list_of_frames(fr, nu, ts)
     q2.preprocess_queue(other, None)
-    gen0 = ctx.generation
+    key = id(fr[0])
+    assert key in ds.PRESEGMENTED
     q2.segment_queue((24, 24), other)
-    assert ctx.generation == gen0 + 1
+    assert key in ds.PRESEGMENTED                                   # not taken: the queue ran the window itself
+    q3 = ds.FrameQueue()
+    q3.push_list_of_frames(list(fr), nu, ts)
+    q3.preprocess_queue(other, None)
+    del ds.PRESEGMENTED[key]
+    q3.segment_queue((24, 24), other)
+    for f2, f3 in zip(q2, q3):
+        assert [(s.label, s.bbox, s.centroid) for s in f2.segments] == [(s.label, s.bbox, s.centroid) for s in f3.segments]
     reader.close()
     assert not ds.PRESEGMENTED
