@@ -261,6 +261,10 @@ def reference_call_pattern(ctx_device, clf, args, geo):
     loop["reference_pattern"] = run_loop(arrays, clf)
     loop["windows_per_call_8"] = run_loop(arrays, clf, windows_per_call=8)
     loop["reference_pattern_no_classify"] = run_loop(arrays, None)
+    # the same unchanged loop over a reader that segments eight queue-fuls ahead in one GPU call (io_frames.PresegmentingReader)
+    from swiftwatcher_amd.io_frames import PresegmentingReader
+    loop["presegmenting_reader_8"] = run_loop(lambda c: PresegmentingReader(ArrayReader(flist * c), crop_region, queue_size=n, windows=8,
+                                                                            device=ctx_device), clf)
     # the same loop fed by a ROI stream file (io_roi_stream.py: the crop region + margin of every frame, 317 KB instead of 6.2 MB;
     # the reader's page-locked blocks are uploaded as they are, the next window is read ahead in a thread)
     with tempfile.TemporaryDirectory() as tmp:
@@ -268,9 +272,12 @@ def reference_call_pattern(ctx_device, clf, args, geo):
         stream = lambda c: RoiStreamReader(paths[c], device=ctx_device)  # noqa: E731
         loop["roi_stream"] = run_loop(stream, clf)
         loop["roi_stream_windows_per_call_8"] = run_loop(stream, clf, windows_per_call=8)
+        loop["roi_stream_presegmenting_reader_8"] = run_loop(lambda c: PresegmentingReader(stream(c), queue_size=n, windows=8, device=ctx_device), clf)
         loop["roi_stream"]["input_mb_per_frame"] = round(os.path.getsize(paths[1]) / len(flist) / 1e6, 3)
     out["count_loop"] = dict(loop["reference_pattern"], roi_stream=loop["roi_stream"],
                              roi_stream_windows_per_call_8=loop["roi_stream_windows_per_call_8"],
+                             presegmenting_reader_8=loop["presegmenting_reader_8"],
+                             roi_stream_presegmenting_reader_8=loop["roi_stream_presegmenting_reader_8"],
                              what="swift_counting_algorithm as __main__.py:56-100 runs it: get_n_frames -> FrameQueue() -> classifier(frame.segments) "
                                   "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory played %d times, "
                                   "--classify on (the bench's calibrated head)" % (len(flist), cycles),
