@@ -56,9 +56,16 @@ def classify(sd, segment_images):
     """Per-segment scores (N, 2) float32 and the keep mask (argmax == 1; ties -> 0 -> dropped)."""
     sd = {k: v.float().cpu() for k, v in sd.items()}
     scores = []
-    with torch.no_grad():
-        for im in segment_images:
-            scores.append(forward(sd, transform(im))[0])
+    # a batch-1 forward of these small convolutions gets SLOWER with one thread per hardware thread (128 on the GPU box: tens of
+    # milliseconds per segment against 6 with 8-16 threads, bench.py's cpu_baseline); the arithmetic does not depend on the count
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))
+    try:
+        with torch.no_grad():
+            for im in segment_images:
+                scores.append(forward(sd, transform(im))[0])
+    finally:
+        torch.set_num_threads(threads)
     s = torch.stack(scores) if scores else torch.zeros((0, 2))
     return s.numpy(), (torch.max(s, 1)[1] == 1).numpy() if len(scores) else np.zeros(0, bool)
 
