@@ -178,3 +178,47 @@ def test_library_before_torch_shares_one_hip_runtime():
         "print('one runtime ok')\n" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "one runtime ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_host_staging_helpers(built_lib):
+    """swk_stage_frames / swk_cut_boxes (host code of the library, no GPU): the window's crops and a window's segment images are
+    plain copies -- equal to numpy slicing for every layout they accept, numpy itself for the layouts they do not."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, size=(90, 130, 3), dtype=np.uint8) for _ in range(21)]
+    dst = np.empty((21, 40, 50, 3), np.uint8)
+    _lib.stage_frames(frames, 11, 51, 60, 110, dst)
+    np.testing.assert_array_equal(dst, np.stack([f[11:51, 60:110] for f in frames]))
+    big = [rng.integers(0, 256, size=(400, 700, 3), dtype=np.uint8) for _ in range(9)]          # > 1 MB: the thread pool's path
+    dst = np.empty((9, 300, 500, 3), np.uint8)
+    _lib.stage_frames(big, 50, 350, 100, 600, dst)
+    np.testing.assert_array_equal(dst, np.stack([f[50:350, 100:600] for f in big]))
+    gray = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
+    dst = np.empty((21, 40, 50), np.uint8)
+    _lib.stage_frames(gray, 11, 51, 60, 110, dst)
+    np.testing.assert_array_equal(dst, np.stack([f[11:51, 60:110] for f in gray]))
+    strided = [f[:, ::2] for f in frames]                                                          # not row-contiguous: numpy's copy
+    dst = np.empty((21, 40, 20, 3), np.uint8)
+    _lib.stage_frames(strided, 11, 51, 5, 25, dst)
+    np.testing.assert_array_equal(dst, np.stack([f[11:51, 5:25] for f in strided]))
+    lib = _lib.load()
+    ptrs = (ctypes.c_void_p * 2)(frames[0].ctypes.data, None)
+    assert lib.swk_stage_frames(ptrs, 2, 390, 0, 4, 0, 30, dst.ctypes.data, 1) != 0               # a null frame pointer is refused
+    # segment boxes of several frames into one buffer
+    boxes = np.array([[0, 24, 0, 24], [10, 50, 20, 44], [80, 90, 100, 130], [5, 5, 7, 9], [30, 31, 0, 130]], np.int32)
+    frame_of = np.array([0, 3, 3, 7, 20], np.int32)
+    buf, offs = _lib.cut_boxes(frames, frame_of, boxes)
+    at = 0
+    for (r0, r1, c0, c1), f, o in zip(boxes.tolist(), frame_of.tolist(), offs.tolist()):
+        want = frames[f][r0:r1, c0:c1]
+        assert o == at
+        np.testing.assert_array_equal(buf[o:o + want.size].reshape(want.shape), want)
+        at += want.size
+    assert at == buf.size
+    bad = boxes.copy()
+    bad[1, 0] = -3
+    with pytest.raises(_lib.SwkError):
+        _lib.cut_boxes(frames, frame_of, bad)
+    empty_buf, empty_offs = _lib.cut_boxes(frames, np.zeros(0, np.int32), np.zeros((0, 4), np.int32))
+    assert empty_buf.size == 0 and empty_offs.size == 0
