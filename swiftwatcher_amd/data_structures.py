@@ -224,6 +224,9 @@ class WindowBatch:
         key = id(classifier)
         if key in self._tables or not self.alive() or self.total == 0:
             return
+        dev = getattr(classifier, "device", None)
+        if dev is None or dev.type != "cuda" or (dev.index or 0) != self.ctx.device:
+            return                               # a classifier on another device scores the segments' images
         try:
             self._tables[key] = classifier.predict_last_batch(self.ctx, self.generation, self.total, self.min_seg_size)
         except _lib.StaleBatch:
@@ -303,10 +306,11 @@ class FrameQueue(deque):
     def preprocess_queue(self, crop_region, resize_dim=None):
         """:171-185.  "crop" is the reference's view of the frame, made when it is first read; "grayscale" is produced on the
         GPU by segment_queue's single library call and is resolved lazily if somebody reads it earlier."""
+        region = [tuple(crop_region[0]), tuple(crop_region[1])]          # the caller's list may change before a value is read
         for slot in self:
             frame = slot.frame
-            slot.processed_frames["crop"] = (lambda f=frame: img.crop_frame(f, crop_region))
-            slot.processed_frames["grayscale"] = (lambda f=frame: img.convert_grayscale(img.crop_frame(f, crop_region)))
+            slot.processed_frames["crop"] = (lambda f=frame: img.crop_frame(f, region))
+            slot.processed_frames["grayscale"] = (lambda f=frame: img.convert_grayscale(img.crop_frame(f, region)))
 
     def _take_presegmented(self, min_seg_size, crop_region):
         """The window a PresegmentingReader segmented ahead, if the queue holds exactly its frames and the same regions are asked for."""
