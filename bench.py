@@ -613,7 +613,7 @@ def main():
             del host
             if args.size == "P2":
                 res.update(reference_call_pattern(local, clf, args, geo))
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:          # the CPU baseline is a single-GPU-run companion (rank 0 at N = 1 only)
             res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
         print(json.dumps(res), flush=True)
     ctx.close()
