@@ -121,3 +121,62 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["launched_by"] == "bench.py" and line["backend"] == "gloo"
     assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["frames"] == 4 * 64 * 2 for r in line["per_rank"])
+
+
+_VIDEO_RANK = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+from swiftwatcher_amd import distributed as d, pipeline, synthetic
+from swiftwatcher_amd import event_classification as ec
+r, w, local = d.init("gloo")                      # two ranks share the one GPU of the box: RCCL refuses that, gloo carries the gather
+crop_region = [(30, 20), (30 + 96, 20 + 64)]
+roi_mask = np.zeros((64, 96), np.uint8)
+roi_mask[28:, :] = 255
+
+def video(i):                                     # "one video per GPU" (BASELINE configs 4 / 5): clip i, counted end to end
+    clip = synthetic.full_frames(500 + i, 48 + 5 * i, crop_region, frame_hw=(110, 160), birds=4, bird_len=(8, 12), bird_wid=(3, 5))[::-1].copy()
+    count, events = pipeline.count_swifts(list(clip), crop_region, roi_mask, device=0)
+    return (count, len(events) - count, len(clip))
+
+table = d.run_sharded({n_videos}, video)
+d.barrier()
+if r == 0:
+    print("TABLE " + json.dumps(table.tolist()))
+torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_videos_sharded_over_two_ranks_on_the_gpu():
+    """BASELINE configs 4 / 5 in miniature, on the one GPU a test box has: two ranks (fresh processes), each counts its videos
+    round-robin through the whole path (segment on the GPU -> track -> events -> count), one all_gather of the per-video counts;
+    the table equals the one a single process computes.  (gloo: two ranks on one device; the RCCL path is covered by the one-rank
+    test above and by bench.py on the driver's multi-GPU node.)"""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    from swiftwatcher_amd import pipeline, synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_videos, port = 3, _free_port()
+    code = _VIDEO_RANK.format(root=root, n_videos=n_videos)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    table = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("TABLE ")][0][6:])
+    crop_region = [(30, 20), (30 + 96, 20 + 64)]
+    roi_mask = np.zeros((64, 96), np.uint8)
+    roi_mask[28:, :] = 255
+    expect = []
+    for i in range(n_videos):
+        clip = synthetic.full_frames(500 + i, 48 + 5 * i, crop_region, frame_hw=(110, 160), birds=4, bird_len=(8, 12), bird_wid=(3, 5))[::-1].copy()
+        count, events = pipeline.count_swifts(list(clip), crop_region, roi_mask)
+        expect.append([count, len(events) - count, len(clip)])
+    assert table == expect
+    assert sum(r[0] + r[1] for r in table) >= 1
