@@ -274,6 +274,13 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 
+/* maxpool3s2 + conv1x1_bias_relu_place as ONE kernel (a MaxPool2d(3, 2) followed by a Fire module's squeeze: the pooled tensor never
+ * goes to memory): src [n][t][t][cin] (cin a multiple of 32), pooled size p = (t - 3) / 2 + 1 (p * p <= 96), weight [cout][cin] with
+ * cout <= 64 a multiple of 4;  dst[n][off_y + y][off_x + x][co] = max(sum_ci weight[co][ci] max_{3x3, stride 2} src + bias[co], 0). */
+int32_t swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight,
+                                                    const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC,
+                                                    int32_t off_y, int32_t off_x);
+
 /* Measurement knob of the classifier kernels (A/B runs; results never depend on it).  knob 0: workgroup layout of the 1 x 1
  * kernel (0 = 16-wave workgroups, the default; 1 = 8 waves with the deepest activation ring that fits). */
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value);

@@ -168,6 +168,8 @@ class CroppedSqueezeNet10:
         # winograd = False runs the 3x3 expands on the direct kernel (csrc/cnn_conv3x3.hip) instead of F(2x2, 3x3).
         self.own_kernels = os.environ.get("SWK_OWN_CNN_KERNELS", "1") == "1"
         self.winograd = True
+        # max-pool + the squeeze behind it as one kernel (csrc/cnn_poolsq.hip): the pooled tensor never goes to memory
+        self.fuse_pool = os.environ.get("SWK_FUSE_POOL", "1") == "1"
         self._w1 = None
         self._wt3 = {}
         self._ww3 = {}
@@ -343,6 +345,14 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_maxpool3s2 failed (%d)" % rc)
 
+        def pool_squeeze(src, conv, dest, off):
+            wgt = conv.weight.reshape(conv.out_channels, conv.in_channels)
+            rc = lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, src.data_ptr(), k, src.shape[2], src.shape[1], wgt.data_ptr(),
+                                                                 conv.bias.data_ptr(), conv.out_channels, dest.data_ptr(), dest.shape[2],
+                                                                 dest.shape[3], dest.shape[1], off, off)
+            if rc:
+                raise RuntimeError("swk_nhwc_maxpool3s2_conv1x1_bias_relu_place failed (%d)" % rc)
+
         aux = self._aux_buffers(row0 + k)
         conv1 = m.features[0]
         a, b = self.pool1_slice
@@ -360,13 +370,19 @@ class CroppedSqueezeNet10:
         else:
             e = conv2d(nhwc(tiles), conv1.weight, None, stride=conv1.stride)
             place(e, conv1.bias, c1buf, a, b - a, 0, 0)
+        fuse = self.fuse_pool and self.own_kernels
+        to_pool = c1buf               # a tensor whose max-pool the next squeeze reads (fused into it), or None
         x = aux["pool_in"][rows]
-        pool(c1buf, x)
+        if not fuse:
+            pool(c1buf, x)
         pi = 0
         for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
             if kind == "pool":
                 x = aux["pool_out"][pi][rows]
-                pool(bufs[j][rows], x)
+                if fuse:
+                    to_pool = bufs[j][rows]
+                else:
+                    pool(bufs[j][rows], x)
                 pi += 1
                 continue
             sq = bufs[j][rows]
@@ -379,7 +395,12 @@ class CroppedSqueezeNet10:
             if self.own_kernels:
                 # squeeze and expand1x1 as ONE kernel each on the f32 matrix cores: convolution + bias + ReLU + placement
                 # (csrc/cnn_conv1x1.hip)
-                conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
+                if fuse and to_pool is not None:
+                    assert (to_pool.shape[2] - 3) // 2 + 1 == n
+                    pool_squeeze(to_pool, layer.squeeze, sq, off)
+                    to_pool = None
+                else:
+                    conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
                 # expand1x1 only where the squeeze output depends on the segment (n x n inside the cn x cn square: the ring keeps the
                 # blank image's values the buffers were created with)
                 conv1x1(sq, off, n, layer.expand1x1, dest, doff + off - c, 0)

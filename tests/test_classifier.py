@@ -665,3 +665,42 @@ def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
     x = torch.randn((96, 3, 40, 40), generator=g).to(clf.device).contiguous(memory_format=torch.channels_last)
     whole = clf.cropped(x)
     np.testing.assert_allclose(torch.cat([clf.cropped(x[:32], 0), clf.cropped(x[32:], 32)]).cpu().numpy(), whole.cpu().numpy(), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fused_maxpool_squeeze_kernel_against_torch():
+    """swk_nhwc_maxpool3s2_conv1x1_bias_relu_place (MaxPool2d(3, 2) + a Fire module's squeeze + bias + ReLU + placement as one kernel)
+    against torch on the network's three pool -> squeeze pairs (96 -> 16 on 17 x 17, 256 -> 32 on 17 x 17, 512 -> 64 on 19 x 19) and
+    on ragged ones; the pooled values are exact, the product is float32 in another summation order: 2e-5 of the output scale."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(21)
+    cases = [  # n, cin, cout, t, dH, off, dC
+        (5, 96, 16, 17, 10, 1, 16), (4, 256, 32, 17, 10, 1, 32), (3, 512, 64, 19, 11, 1, 64), (300, 512, 64, 19, 11, 1, 64),
+        (2, 64, 8, 7, 3, 0, 8), (7, 128, 48, 13, 8, 2, 64), (1, 32, 64, 5, 2, 0, 64), (2500, 96, 16, 17, 8, 0, 16)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, cin, cout, t, dH, off, dC in cases:
+        x = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wgt = (torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5).to(dev)
+        bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+        dst = torch.full((n, dC, dH, dH), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        exp = dst.clone()
+        y = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.max_pool2d(x, 3, 2), wgt, bias))
+        p = y.shape[2]
+        exp[:, :cout, off:off + p, off:off + p] = y
+        torch.cuda.synchronize()
+        rc = lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), n, t, cin, wgt.reshape(cout, cin).contiguous().data_ptr(),
+                                                             bias.data_ptr(), cout, dst.data_ptr(), dH, dH, dC, off, off)
+        assert rc == 0, (rc, n, cin, cout, t)
+        torch.cuda.synchronize()
+        scale = max(float(y.abs().max()), 1.0)
+        assert float((dst - exp).abs().max()) <= 2e-5 * scale, (n, cin, cout, t)
+        mask = torch.ones_like(dst, dtype=torch.bool)
+        mask[:, :cout, off:off + p, off:off + p] = False
+        assert bool((dst[mask] == -7.0).all())
+    assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 17, 48, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
+                                                           8, 8, 16, 0, 0) != 0          # cin not a multiple of 32
+    assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 23, 96, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
+                                                           11, 11, 16, 0, 0) != 0        # 121 pooled pixels: more than three pixel tiles

@@ -52,6 +52,10 @@ def describe(name, a):
         o = t - 2
         # direct-convolution multiply-accumulates for both (the Winograd kernel executes 16/36 of them, padded to even sizes)
         return ("w3x3" if "winograd" in name else "3x3 ") + "%3d->%3d %2dx%2d" % (cin, cout, o, o), n * o * o * 9 * cin * cout, 4 * n * (t * t * cin + o * o * cout)
+    if name == "swk_nhwc_maxpool3s2_conv1x1_bias_relu_place":
+        n, t, cin, cout = a[2], a[3], a[4], a[7]
+        p = (t - 3) // 2 + 1
+        return "p+1x1 %3d->%3d %2dx%2d" % (cin, cout, p, p), n * p * p * cin * cout, 4 * n * (t * t * cin + p * p * cout)
     if name == "swk_nhwc_maxpool3s2":
         n, h, w, c = a[2], a[3], a[4], a[5]
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
