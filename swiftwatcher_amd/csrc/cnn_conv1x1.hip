@@ -165,7 +165,6 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
-int g_squeeze_lds = 1;            // A/B knob (swk_set_cnn_tuning 1): wide squeezes of a whole batch by the LDS-staged kernel
 int g_conv1x1_ring = 0;          // A/B knob: 0 = 16-wave workgroups, column blocks of the wide expands split over two waves; 1 = the
                                  // first layout (8 waves, every wave all column blocks, activation ring as deep as fits)
 
@@ -225,12 +224,6 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     using namespace swk;
     const int64_t rows = (int64_t)n * h * w;
     hipStream_t s = (hipStream_t)stream;
-    // a squeeze of a whole batch: activations read along the channels and staged through LDS (cnn_poolsq.hip); small batches stay with
-    // the kernel below, whose workgroups are not tied to segments
-    if (g_squeeze_lds && h == w && cout <= 64 && cin >= 96 && n >= 512 && dC == cout && c_off == 0) {
-        const int rc = launch_squeeze_lds(s, src, n, sh, sw, cin, crop_y, crop_x, h, weight, bias, cout, dst, dH, dW, dC, off_y, off_x);
-        if (rc >= 0) return rc;
-    }
     switch ((cout + 31) / 32) {
     case 1: return launch_conv1x1<1>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     case 2: return launch_conv1x1<2>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
@@ -247,7 +240,6 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value)
 {
     if (knob == 0 && (value == 0 || value == 1)) { swk::g_conv1x1_ring = value; return SWK_OK; }
-    if (knob == 1 && (value == 0 || value == 1)) { swk::g_squeeze_lds = value; return SWK_OK; }
     return SWK_ERR_ARG;
 }
 

@@ -20,23 +20,18 @@ namespace swk {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-// POOL = false: the same kernel without the pooling (one load per item instead of nine): a squeeze whose activations are read along the
-// channels (eight lanes = one 128-byte line of a pixel) and turned into the MFMA's pixel operand through LDS, instead of every lane
-// loading its own pixel's channels (32 lines per wave instruction: k_conv1x1_relu_place stops at 3-3.5 TB/s on the wide squeezes).
-// src is then [n][T][sw][C] and the P x P pixels start at (crop_y, crop_x).
-template <int PT, int NB, bool POOL>
-__global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__restrict__ src, int n, int T, int sw, int crop_y, int crop_x, int C, int P,
-                                                               const float *__restrict__ wgt, const float *__restrict__ bias, int S,
-                                                               float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x)
+template <int PT, int NB>
+__global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__restrict__ src, int n, int T, int C, int P, const float *__restrict__ wgt,
+                                                               const float *__restrict__ bias, int S, float *__restrict__ dst, int dH, int dW, int dC,
+                                                               int off_y, int off_x)
 {
     constexpr int NW = PT * NB, NT = 64 * NW, PP = 32 * PT + 1, SP = 32 * NB + 1, KC = 32;
-    extern __shared__ float lds[];
-    float (*sB)[KC * PP] = (float (*)[KC * PP])lds;                       // [2] pooled pixels of a chunk: [channel k][pixel]
-    float (*sA)[KC * SP] = (float (*)[KC * SP])(lds + 2 * KC * PP);      // [2] the chunk's weights: [channel k][output channel]
+    __shared__ float sB[2][KC * PP];          // pooled pixels of a chunk: [channel k][pixel]
+    __shared__ float sA[2][KC * SP];          // the chunk's weights: [channel k][output channel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int pt = wave % PT, nb = wave / PT;
     const int npix = P * P, nchunk = C / KC;
-    const int64_t rs = (int64_t)sw * C;          // floats per source row
+    const int64_t rs = (int64_t)T * C;          // floats per source row
 
     auto stage = [&](int seg, int c, int buf) {
         const int kb = c * KC;
@@ -55,20 +50,16 @@ __global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__re
             float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < npix) {
                 const int py = p / P, px = p - py * P;
-                if (POOL) {
-                    const float *s0 = base + (int64_t)(2 * py) * rs + (int64_t)(2 * px) * C + 4 * q;
-                    m = *(const float4 *)s0;
+                const float *s0 = base + (int64_t)(2 * py) * rs + (int64_t)(2 * px) * C + 4 * q;
+                m = *(const float4 *)s0;
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            if (dy == 0 && dx == 0) continue;
-                            const float4 v = *(const float4 *)(s0 + dy * rs + dx * C);
-                            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-                        }
-                } else {
-                    m = *(const float4 *)(base + (int64_t)(crop_y + py) * rs + (int64_t)(crop_x + px) * C + 4 * q);
-                }
+                    for (int dx = 0; dx < 3; ++dx) {
+                        if (dy == 0 && dx == 0) continue;
+                        const float4 v = *(const float4 *)(s0 + dy * rs + dx * C);
+                        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                    }
             }
             float *b = &sB[buf][(4 * q) * PP + p];
             b[0] = m.x; b[PP] = m.y; b[2 * PP] = m.z; b[3 * PP] = m.w;
@@ -112,33 +103,14 @@ __global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__re
     }
 }
 
-template <int PT, int NB, bool POOL>
-static int launch_pool_squeeze(hipStream_t s, const float *src, int n, int T, int sw, int crop_y, int crop_x, int C, int P, const float *wgt,
-                               const float *bias, int S, float *dst, int dH, int dW, int dC, int off_y, int off_x)
+template <int PT, int NB>
+static int launch_pool_squeeze(hipStream_t s, const float *src, int n, int T, int C, int P, const float *wgt, const float *bias, int S, float *dst,
+                               int dH, int dW, int dC, int off_y, int off_x)
 {
     int blocks = n < 256 * 8 ? n : 256 * 8;          // persistent over the segments beyond a few workgroups per CU
-    constexpr size_t lds = (size_t)2 * 32 * ((32 * PT + 1) + (32 * NB + 1)) * sizeof(float);
-    static unsigned long long attr_mask = 0;
-    if (lds > 48 * 1024 && !ensure_dyn_lds((const void *)k_pool_squeeze<PT, NB, POOL>, lds, attr_mask)) return SWK_ERR_HIP;
-    hipLaunchKernelGGL((k_pool_squeeze<PT, NB, POOL>), dim3((unsigned)blocks), dim3(64 * PT * NB), lds, s, src, n, T, sw, crop_y, crop_x, C, P, wgt,
-                       bias, S, dst, dH, dW, dC, off_y, off_x);
+    hipLaunchKernelGGL((k_pool_squeeze<PT, NB>), dim3((unsigned)blocks), dim3(64 * PT * NB), 0, s, src, n, T, C, P, wgt, bias, S, dst, dH, dW, dC,
+                       off_y, off_x);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
-}
-
-// A squeeze (cout <= 64) over a square of up to 224 pixels per segment by the LDS-staged kernel; -1 when the shape is not its kind
-// (the caller then takes k_conv1x1_relu_place).
-int launch_squeeze_lds(hipStream_t s, const float *src, int n, int sh, int sw, int cin, int crop_y, int crop_x, int p, const float *wgt,
-                       const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x)
-{
-    if ((cin & 31) || cout > 64 || p * p > 224 || (((uintptr_t)wgt | (uintptr_t)bias) & 15)) return -1;
-    const int PT = (p * p + 31) / 32, NB = (cout + 31) / 32;
-#define SWK_SQ_ARGS s, src, n, sh, sw, crop_y, crop_x, cin, p, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x
-#define SWK_SQ_CASE(pt)                                                                   \
-    if (PT == pt) return NB == 1 ? launch_pool_squeeze<pt, 1, false>(SWK_SQ_ARGS) : launch_pool_squeeze<pt, 2, false>(SWK_SQ_ARGS);
-    SWK_SQ_CASE(1) SWK_SQ_CASE(2) SWK_SQ_CASE(3) SWK_SQ_CASE(4) SWK_SQ_CASE(5) SWK_SQ_CASE(6) SWK_SQ_CASE(7)
-#undef SWK_SQ_CASE
-#undef SWK_SQ_ARGS
-    return -1;
 }
 
 }  // namespace swk
@@ -158,13 +130,13 @@ int32_t swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(void *stream, const float *s
     using namespace swk;
     hipStream_t s = (hipStream_t)stream;
     const int PT = (P * P + 31) / 32, NB = (cout + 31) / 32;
-#define SWK_PS_ARGS s, src, n, t, t, 0, 0, cin, P, weight, bias, cout, dst, dH, dW, dC, off_y, off_x
-    if (PT == 1 && NB == 1) return launch_pool_squeeze<1, 1, true>(SWK_PS_ARGS);
-    if (PT == 2 && NB == 1) return launch_pool_squeeze<2, 1, true>(SWK_PS_ARGS);
-    if (PT == 3 && NB == 1) return launch_pool_squeeze<3, 1, true>(SWK_PS_ARGS);
-    if (PT == 1 && NB == 2) return launch_pool_squeeze<1, 2, true>(SWK_PS_ARGS);
-    if (PT == 2 && NB == 2) return launch_pool_squeeze<2, 2, true>(SWK_PS_ARGS);
-    if (PT == 3 && NB == 2) return launch_pool_squeeze<3, 2, true>(SWK_PS_ARGS);
+#define SWK_PS_ARGS s, src, n, t, cin, P, weight, bias, cout, dst, dH, dW, dC, off_y, off_x
+    if (PT == 1 && NB == 1) return launch_pool_squeeze<1, 1>(SWK_PS_ARGS);
+    if (PT == 2 && NB == 1) return launch_pool_squeeze<2, 1>(SWK_PS_ARGS);
+    if (PT == 3 && NB == 1) return launch_pool_squeeze<3, 1>(SWK_PS_ARGS);
+    if (PT == 1 && NB == 2) return launch_pool_squeeze<1, 2>(SWK_PS_ARGS);
+    if (PT == 2 && NB == 2) return launch_pool_squeeze<2, 2>(SWK_PS_ARGS);
+    if (PT == 3 && NB == 2) return launch_pool_squeeze<3, 2>(SWK_PS_ARGS);
 #undef SWK_PS_ARGS
     return SWK_ERR_ARG;
 }

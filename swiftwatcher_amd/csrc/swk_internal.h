@@ -139,11 +139,6 @@ void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
                          int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out);
 
-// cnn_poolsq.hip: a squeeze (1 x 1 convolution, cout <= 64, cin a multiple of 32) over a p x p square per segment with its activations
-// staged through LDS; returns -1 when the shape is not its kind
-int launch_squeeze_lds(hipStream_t s, const float *src, int n, int sh, int sw, int cin, int crop_y, int crop_x, int p, const float *wgt,
-                       const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x);
-
 // classify_input.hip
 void launch_classifier_input(hipStream_t s, const uint8_t *crops, const int64_t *offsets, const int32_t *hw, int nseg,
                              uint8_t *patches, float *net, int pad, bool nhwc, const float *mean, const float *sd);
