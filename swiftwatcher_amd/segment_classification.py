@@ -544,7 +544,8 @@ class SegmentClassifier:
         return min(self.batch_size, -(-k // 512) * 512)
 
     def _forward(self, x):
-        if self._cudnn_benchmark:
+        # (nothing of the default GPU path is a MIOpen convolution: the setting only matters for the full network and the cross-check)
+        if self._cudnn_benchmark and (self.cropped is None or not self.cropped.own_kernels):
             with torch.backends.cudnn.flags(enabled=True, benchmark=True):
                 return self.cropped(x) if self.cropped is not None else self.model(x)
         return self.cropped(x) if self.cropped is not None else self.model(x)
