@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert _lib.load().swk_abi_version() == _lib.ABI_VERSION == 2
 
 
+def test_every_entry_point_is_mapped_to_the_reference_in_the_integration_notes():
+    """INTEGRATION.md section 4 is the maintainer's table: each C symbol next to the reference function it replaces."""
+    from swiftwatcher_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _lib.EXPORTS if n not in doc and not (n.startswith("swk_prof_") and "swk_prof_*" in doc)]
+    assert not missing, missing
+
+
 def test_struct_layouts_and_defaults(built_lib):
     import subprocess
     import tempfile
