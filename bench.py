@@ -43,7 +43,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* at the f32 v
 F64_MATRIX_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 64 cycles per instruction per SIMD (measured) = 32 flop/clk/SIMD at 2.4 GHz
 # algorithmic bytes per matrix element and IALM iteration of the streaming pass:
 #   variant 2 (A/Y state, SURVEY 8d's figure): X u8 + A,Y f64 read, A,Y f64 written = 33; first iteration reads X only = 17
-#   variant 3 (M state, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 written = 21; first = 11;
+#   class 3 (M state: variants 4 / 5, the default):          X u8 + M f64 + U f16 read, M f64 + U f16 written = 21; first = 11;
 #                                              the sparse u8 image is needed once per window (+1 B per element, booked
 #                                              once: the passes far from convergence do not store it)
 PASS_BYTES = {1: (33, 17, 0), 2: (33, 17, 0), 3: (21, 11, 1)}

@@ -348,10 +348,10 @@ int32_t swk_prof_get(swk_ctx *ctx, int32_t family, double *ms_total, int64_t *la
 int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters);
 /* Select the IALM pass kernel: 0 = auto (4, or 2 when A / E are requested, 6 above 64 frames), 6 = the plain float64 kernels of long
  * windows (accepted for any n: the tests compare them with 1), 1 = LDS/VALU kernel,
- * 2 = MFMA f64 kernel carrying A and Y, 3 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per
- * element and iteration; produces the sparse u8 image and the iteration count, not A / E), instantiated per 16-frame
- * block; 4 = the same pass instantiated per 4-frame k-step with a software-pipelined tile loop, 5 = 4 without the pipeline.
- * For A/B measurements only. */
+ * 2 = MFMA f64 kernel carrying A and Y, 4 = MFMA f64 kernel carrying M alone (21-22 instead of 34 B per element and
+ * iteration; produces the sparse u8 image and the iteration count, not A / E), instantiated per 4-frame k-step with a
+ * software-pipelined tile loop, 5 = 4 without the pipeline (its cross-check).  3 (round 1's M-state kernel, one instantiation
+ * per 16-frame block) is gone: SWK_ERR_ARG.  For A/B measurements and cross-checks only. */
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant);
 /* k-step-templated M-state pass (variants 4 / 5): bit 0 = the wave in the odd hardware slot of each SIMD runs at raised
  * priority (breaks the lockstep of the two co-resident waves), bit 1 = it also starts late.  A/B knob; results never

@@ -428,7 +428,6 @@ static void launch_v1(hipStream_t s, const IalmBuffers &b)
 void launch_ialm_pass_v2(hipStream_t s, const IalmBuffers &b, int mode);   // ialm_mfma.hip
 bool ialm_v2_supported(int n);
 
-void launch_ialm_pass_v3(hipStream_t s, const IalmBuffers &b, int mode, int k);
 
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k, int tune)
 {
@@ -440,7 +439,6 @@ void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant
         return;
     }
     if (variant >= 4) { launch_ialm_pass_m(s, b, mode, k, tune, variant == 4); return; }
-    if (variant == 3) { launch_ialm_pass_v3(s, b, mode, k); return; }
     if (variant == 2) { launch_ialm_pass_v2(s, b, mode); return; }
     const bool we = b.E != nullptr;
     if (mode == 0) launch_v1<0, false>(s, b);

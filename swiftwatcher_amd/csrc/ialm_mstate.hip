@@ -1,6 +1,24 @@
-// IALM streaming pass on the f64 matrix cores, M-state formulation (see ialm_mfma.hip for the derivation: with
-// A_k = M_k B_k the multiplier update collapses to Y_k = mu_{k-1} (M_k - A_k), so M alone is carried between passes),
-// instantiated per NUMBER OF K-STEPS NK = ceil(n / 4) instead of per 16-frame block:
+// IALM streaming pass on the f64 matrix cores, M-state formulation: the same pass as k_ialm_pass_v2 (ialm_mfma.hip) on HALF the
+// f64 state.  With A_k = M_k B_k (image_filtering.py:290) the multiplier update (:294) collapses:
+//   Y_k = Y_{k-1} + mu_{k-1} (X - A_k - E_k)  and  M_k = X - E_k + Y_{k-1}/mu_{k-1}   =>   Y_k = mu_{k-1} (M_k - A_k),
+// so A_k and Y_k are both functions of M_k and the small matrix B_k, and M_k alone (8 B/element) is the state
+// carried between passes instead of A and Y (16 B).  Per pass and element:
+//   read  X u8, M_k f64, U_{k-1} f16      write  M_{k+1} f64, U_k f16, clip(-E_{k+1}) u8        = 22 B (A/Y state: 34 B)
+// U = Y/mu is kept, in binary16, ONLY for the stopping norm ||Z_k||_F, Z_k = X - A_k - E_k = (M_k - A_k) - U_{k-1}
+// (:293, :297).  The test is ||Z||_F < 1e-3 ||X||_F (:297, tol = 0.001): at the decision |z| ~ 0.1 grey levels
+// against |U| ~ 0.5, so U's rounding (2^-12 relative) adds ||delta||^2 ~ 2e-6 ||Z||^2 -- far inside the margin by
+// which consecutive iterations differ (>= 20 % in ||Z||); a window that lands within the guard band of the threshold
+// all the same is rerun by the A/Y-state pass (swk_set_norm_guard).  The state itself never sees the rounded value
+// (U_k is recomputed in f64 from M_k).  U travels as binary16 of U / 128: |U| <= 1/mu_1 < ||X||_F / 1.8 <= 2.3e6 for
+// every admissible window, so U / 128 never overflows binary16, and the format's subnormal step is 7.6e-6 in U's units.
+// The sparse image has to come from an exact E: pass k computes E_{k+1} exactly (it builds M_{k+1} from it) and
+// writes its u8 form to S[k & 1]; when iteration K turns out to be the last, E_K is what pass K-1 left in
+// S[(K-1) & 1] (k_select_sparse moves it to S[0] for odd K-1).  Those stores are 16-byte row pieces and cost 2.5x
+// their share of the bytes, so k_ialm_small switches them off while ||Z|| is still far above the threshold
+// (IalmWin::ws) and flags the window for a rerun should the iteration stop anyway (IalmWin::redo).  A and E in f64 are
+// not produced: callers that ask for them run the A/Y-state pass.
+//
+// The kernel is instantiated per NUMBER OF K-STEPS NK = ceil(n / 4) (round 1's was per 16-frame block):
 //
 //   * a window of n frames moves 4 NK frame rows (n rounded up to 4, not to 16): the CLI's queue of 21 frames runs
 //     6 k-steps, 12 + 12 MFMAs per 16-pixel tile and 24 rows of state instead of 8, 16 + 12 and 32;
@@ -17,11 +35,13 @@
 //     waves issuing together always reach 64): the A update runs one out-frame block at a time and the Gram phase one
 //     block pair at a time.
 //   * up to 32 frames the tile loop is software-pipelined (the next tile's loads are issued before the Gram phase);
-//     with more frames that makes no difference (measured) and the registers go to the Gram operands.
+//     with more frames that makes no difference (measured) and the registers go to the Gram operands.  The plain tile
+//     loop stays as the cross-check (swk_set_ialm_variant(5)).
 //   * tried and measured without effect: raised priority or a delayed start for one wave of each SIMD pair
 //     (swk_set_pass_tuning keeps them as A/B knobs).
 //
-// Register layout, LDS tiles and buffer addressing are those of k_ialm_pass_v3 (ialm_mfma.hip).
+// Register layout (lane l, register t <-> pixel p0 + (l & 15), frame 4t + (l >> 4)), LDS tiles and buffer addressing are
+// those of k_ialm_pass_v2 (ialm_mfma.hip, header).
 #include "swk_internal.h"
 
 namespace swk {
@@ -32,7 +52,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr unsigned kOob = 0x80000000u;        // a byte offset past every buffer: loads give 0, stores are dropped
-constexpr float kUScale = 1.0f / 128.0f, kUUnscale = 128.0f;      // U travels as binary16 of U / 128 (ialm_mfma.hip)
+constexpr float kUScale = 1.0f / 128.0f, kUUnscale = 128.0f;      // U travels as binary16 of U / 128 (header)
 
 __device__ __forceinline__ double shrink2(double raw, double thr)
 {

@@ -271,9 +271,9 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     // which only the A/Y-state pass (v2, 34 B/element) materialises
     int variant = force_variant ? force_variant : ctx->ialm_variant;
     if (variant == 0) variant = 4;
-    if (variant >= 3 && variant != 6 && (want_A || want_E)) variant = 2;
+    if (variant >= 4 && variant != 6 && (want_A || want_E)) variant = 2;
     if (wide) variant = 6;
-    const bool mstate = variant >= 3 && variant != 6;          // 3: block-templated kernel (ialm_mfma.hip); 4 / 5: k-step-templated (ialm_mstate.hip), with / without the software pipeline
+    const bool mstate = variant == 4 || variant == 5;          // the M-state pass (ialm_mstate.hip), with / without the software pipeline
     // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
     // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
     // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
@@ -283,7 +283,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
     b.nred = b.nblk > 4 ? 1 : b.nblk;       // several slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
-    b.fpad = (variant >= 4 && variant != 6) ? ialm_mstate_fpad(n) : (n + 15) & ~15;
+    b.fpad = mstate ? ialm_mstate_fpad(n) : (n + 15) & ~15;
     ctx->pstride = b.pstride;
     ctx->fpad = b.fpad;
     if ((int64_t)b.fpad * b.pstride >= (1ll << 28)) return fail(ctx, SWK_ERR_ARG, "window too large: frames x ROI pixels must stay below 2^28");
@@ -636,7 +636,7 @@ int32_t swk_prof_window_iters(swk_ctx *ctx, int64_t *window_iters)
 }
 int32_t swk_set_ialm_variant(swk_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 6) return SWK_ERR_ARG;
+    if (!ctx || variant < 0 || variant > 6 || variant == 3) return SWK_ERR_ARG;          // 3 was round 1's M-state kernel (removed)
     ctx->ialm_variant = variant;
     return SWK_OK;
 }

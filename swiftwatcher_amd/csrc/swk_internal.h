@@ -79,8 +79,8 @@ struct IalmBuffers {
     const uint8_t *X;              // [nwin][n][P]
     double *A, *Y;                 // [nwin][n][P]
     uint8_t *S;                    // [nwin][n][P]
-    uint8_t *Salt;                 // v3: second sparse-image buffer (iteration parity), else null
-    uint16_t *U;                   // v3: Y/mu as binary16 (x 1/128) for the stopping norm, planes like A; b.A holds M
+    uint8_t *Salt;                 // M-state pass: second sparse-image buffer (iteration parity), else null
+    uint16_t *U;                   // M-state pass: Y/mu as binary16 (x 1/128) for the stopping norm, planes like A; b.A holds M
     double *E;                     // optional [nwin][n][P]
     double *Bm;                    // [nwin][n][n]   I - W/mu
     double *Vprev;                 // [nwin][n][n]   eigenvectors of the previous solve (warm start)
@@ -102,7 +102,7 @@ struct IalmBuffers {
 // ialm.hip
 void launch_ialm_stats(hipStream_t s, const IalmBuffers &b);
 void launch_ialm_init(hipStream_t s, const IalmBuffers &b, double lmbda);
-// k = iteration number of the pass (0 = Gram-only start pass); variant 3 = M-state pass (no A/E outputs)
+// k = iteration number of the pass (0 = Gram-only start pass); variants 4 / 5 = M-state pass (no A/E outputs)
 void launch_ialm_pass(hipStream_t s, const IalmBuffers &b, int mode, int variant, int k, int tune = 0);
 // ialm_mstate.hip: the M-state pass instantiated per k-step count
 void launch_ialm_pass_m(hipStream_t s, const IalmBuffers &b, int mode, int k, int tune, bool pipe);

@@ -12,9 +12,8 @@ pytestmark = pytest.mark.gpu
 ATOL_AE = 1e-5
 
 
-@pytest.fixture(scope="module", params=[(0, 0), (2, 0), (1, 1), (2, 1), (3, 0)],
-                ids=["auto_pass+newton_schulz", "mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi",
-                     "block_templated_mstate_pass+newton_schulz"])
+@pytest.fixture(scope="module", params=[(0, 0), (2, 0), (1, 1), (2, 1)],
+                ids=["auto_pass+newton_schulz", "mfma_pass+newton_schulz", "lds_pass+jacobi", "mfma_pass+jacobi"])
 def ctx(request):
     """Every test runs against the IALM pass kernels (0 = auto: the M-state MFMA pass, or the A/Y-state one when
     A / E are requested; 2 = A/Y-state MFMA pass; 1 = LDS/VALU) and both G^(-1/2) solvers (0 = Newton-Schulz on
@@ -190,7 +189,7 @@ def test_pass_kernels_agree_at_full_size():
     from swiftwatcher_amd import _lib, synthetic
     roi = np.concatenate([synthetic.roi_window(70 + w, 64, 212, 424, birds=4 + 5 * w) for w in range(4)])
     out = []
-    for variant in (3, 2):
+    for variant in (0, 2):
         c = _lib.Context(0)
         c.set_ialm_variant(variant)
         out.append(c.batch_run(roi, 4, 64, stages=("rpca", "opened", "labels")))
@@ -307,8 +306,8 @@ def test_ialm_vs_oracle_and_null_frames(ctx, orc):
 def test_mstate_pass_every_kstep_count(orc):
     """The M-state pass is instantiated per k-step count NK = ceil(n / 4), 1..16: every NK (and n that are / are not
     multiples of 4) on a ROI with a ragged last tile, the pipelined and the plain tile loop, with and without the
-    priority / stagger knobs -- all bit-identical to the block-templated kernel (itself checked against the oracle
-    throughout this file), and to the oracle directly for the CLI's queue of 21 and for n = 49."""
+    priority / stagger knobs -- all bit-identical to one another, and to the oracle directly for n = 5, the CLI's queue of 21,
+    37 and 49."""
     from swiftwatcher_amd import _lib, synthetic
     # every window holds >= 1.4e5 elements: below about 1.1e5 the first shrinkage clips most of the sky, iteration 1 sees a
     # rank-deficient M and the trajectory is chaotic in the last bit of the arithmetic (the reference itself is
@@ -318,8 +317,8 @@ def test_mstate_pass_every_kstep_count(orc):
         Wc = 61 + 2 * (n % 7) + (140000 // n) // 300
         cases.append((n, -(-140000 // (n * Wc)) + 1, Wc))
     ctxs = {}
-    for key, (variant, tune) in {"block": (3, 0), "pipe": (4, 0), "pipe+prio": (4, 1), "pipe+prio+stagger": (4, 3),
-                                 "plain": (5, 0), "plain+prio": (5, 1)}.items():
+    for key, (variant, tune) in {"plain": (5, 0), "pipe": (4, 0), "pipe+prio": (4, 1), "pipe+prio+stagger": (4, 3),
+                                 "plain+prio": (5, 1)}.items():
         c = _lib.Context(0)
         c.set_ialm_variant(variant)
         c.set_pass_tuning(tune)
@@ -327,16 +326,16 @@ def test_mstate_pass_every_kstep_count(orc):
     for n, Hc, Wc in cases:
         roi = np.concatenate([synthetic.roi_window(900 + n + w, n, Hc, Wc, birds=3, bird_len=(8, 14), bird_wid=(3, 6))
                               for w in range(2)])
-        base = ctxs["block"].batch_run(roi, 2, n, stages=("rpca", "labels"))
+        base = ctxs["plain"].batch_run(roi, 2, n, stages=("rpca", "labels"))
         for key, c in ctxs.items():
-            if key == "block":
+            if key == "plain":
                 continue
             res = c.batch_run(roi, 2, n, stages=("rpca", "labels"))
             np.testing.assert_array_equal(res["iters"], base["iters"], err_msg="%s n=%d" % (key, n))
             np.testing.assert_array_equal(res["rpca"], base["rpca"], err_msg="%s n=%d" % (key, n))
             np.testing.assert_array_equal(res["labels"], base["labels"], err_msg="%s n=%d" % (key, n))
             assert res["segs"].tobytes() == base["segs"].tobytes()
-        if n in (21, 49):
+        if n in (5, 21, 37, 49):
             for w in range(2):
                 ref = orc.window(np.ascontiguousarray(roi[w * n:(w + 1) * n]))
                 np.testing.assert_array_equal(base["rpca"][w * n:(w + 1) * n], ref["rpca"])
@@ -347,10 +346,10 @@ def test_mstate_pass_every_kstep_count(orc):
 def test_short_windows_at_config1_element_count_against_oracle(orc):
     """n = 3 ... 9 frames at 9e4 to 1e5 elements per window -- the element count of BASELINE config 1's window (94 x 47 x 21 =
     92.8 k), inside the range the k-step test above leaves out -- against the ORACLE (not only kernel against kernel):
-    iteration count and the uint8 sparse image, for the default k-step kernel, the plain tile loop and the block kernel."""
+    iteration count and the uint8 sparse image, for the default k-step kernel, the plain tile loop and the A/Y-state pass."""
     from swiftwatcher_amd import _lib, synthetic
     ctxs = {}
-    for key, variant in {"default": 0, "plain": 5, "block": 3}.items():
+    for key, variant in {"default": 0, "plain": 5, "ay_state": 2}.items():
         c = _lib.Context(0)
         c.set_ialm_variant(variant)
         ctxs[key] = c
@@ -581,6 +580,9 @@ def test_error_paths(ctx):
         ctx.batch_run(rng.integers(0, 255, size=(4, 3, 16), dtype=np.uint8), 1, 4)
     with pytest.raises(ValueError):
         ctx.batch_run(rng.integers(0, 255, size=(4, 16, 16), dtype=np.uint8), 1, 4, crop=(10, 10, 16, 16))
+    for gone in (3, 7, -1):                     # 3 was round 1's M-state kernel
+        with pytest.raises(_lib.SwkError):
+            ctx.set_ialm_variant(gone)
     # the context survives errors
     out = ctx.thresh_tozero_u8(np.arange(32, dtype=np.uint8), 15)
     assert out[16] == 16 and out[15] == 0

@@ -1,5 +1,5 @@
 """A/B of the IALM pass kernels and their knobs on ONE box, one process, same data (boxes differ by 10-15 %):
-    python3 tools/ab_pass.py [--n 64] [--windows 128] [--size P2] [--rounds 2] v3:0 v5:0 v5:1 v4:0 v4:1 v4:3
+    python3 tools/ab_pass.py [--n 64] [--windows 128] [--size P2] [--rounds 2] v2:0 v5:0 v5:1 v4:0 v4:1 v4:3
 Each config = variant:tune.  Prints ms per step, ms per pass launch, per-family kernel ms."""
 import argparse
 import json

@@ -28,7 +28,7 @@ exit 0
 fi
 TMO=300 step bench_spec_off python3 bench.py --no-cpu-baseline --no-classify --sparse-spec 0 --norm-spec 0
 TMO=300 step bench_v2 python3 bench.py --no-cpu-baseline --no-classify --variant 2
-TMO=300 step bench_v3 python3 bench.py --no-cpu-baseline --no-classify --variant 3
+# (round 2 also ran --variant 3 here: round 1's M-state kernel, removed in round 3)
 TMO=300 step bench_n21 python3 bench.py --no-cpu-baseline --no-classify --n 21 --windows 384
 TMO=300 step bench_n49 python3 bench.py --no-cpu-baseline --no-classify --n 49 --windows 128
 TMO=300 step bench_host python3 bench.py --no-cpu-baseline --no-classify --host-input --windows 32

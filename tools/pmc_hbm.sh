@@ -7,5 +7,5 @@ rm -rf "$out"; mkdir -p "$out"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/$c" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$out/$c.log" 2>&1
 done
-python3 tools/pmc_summary.py "$out" "$out/summary.json" | grep -A3 "k_ialm_pass_v3<4, 2\|k_ialm_pass_v3<4, 1"
+python3 tools/pmc_summary.py "$out" "$out/summary.json" | grep -A3 "k_ialm_pass_m<16, 2\|k_ialm_pass_m<16, 1"
 rm -rf "$out"/FETCH_SIZE "$out"/WRITE_SIZE

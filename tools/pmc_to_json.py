@@ -10,7 +10,7 @@ import json, re, sys
 
 meas = sys.argv[1]
 summ = json.load(open(meas + "/pmc_summary.json"))
-key = [k for k in summ if "k_ialm_pass_m<16, 2>" in k or "k_ialm_pass_v3<4, 2" in k][0]
+key = [k for k in summ if "k_ialm_pass_m<16, 2>" in k][0]
 c = summ[key]
 probe = open(meas + "/pass_probe.txt").read()
 counted = float(re.search(r"k_probe<0>.*FETCH_SIZE counted B/elt ([0-9.]+)", probe).group(1))
