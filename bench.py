@@ -74,9 +74,7 @@ def parse():
                     help="A/B: MIOpen's immediate-mode kernel choice instead of its exhaustive find (the classifier's default)")
     ap.add_argument("--variant", type=int, default=0, help="IALM kernel variant (0 auto)")
     ap.add_argument("--tune", type=int, default=None, help="A/B: swk_set_pass_tuning flags (variants 4 / 5)")
-    ap.add_argument("--groups", type=int, default=0, help="IALM window groups (0 auto)")
     ap.add_argument("--eig-method", type=int, default=0, help="0 Newton-Schulz (MFMA), 1 Jacobi")
-    ap.add_argument("--eig-cus", type=int, default=-1, help="CUs reserved for the eigen-solve streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU baseline sample (about 7 s each at P2, n=64)")
     ap.add_argument("--host-input", action="store_true", help="(default at N = 1) kept for compatibility: pcie_inclusive is part of the line")
@@ -327,8 +325,6 @@ def main():
 
     ctx = _lib.Context(local, nwin, n, Hc, Wc)
     ctx.set_ialm_variant(args.variant)
-    ctx.set_ialm_groups(args.groups)
-    ctx.set_eig_cus(args.eig_cus)
     ctx.set_eig_method(args.eig_method)
     if args.tune is not None:
         ctx.set_pass_tuning(args.tune)

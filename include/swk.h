@@ -387,13 +387,6 @@ int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches);
  * windows (each window-iteration counts X 1 + M 8 (+8 read) + U 2 or 1/8 each way + 1 when the sparse image is
  * stored); multiply by n*P for bytes.  Meaningful for the M-state pass only. */
 int32_t swk_prof_pass_bytes_per_element(swk_ctx *ctx, double *bytes);
-/* Window groups whose eigen-solves overlap the other groups' streaming passes:
- * 0 = auto, 1..8 explicit.  For A/B measurements only; results do not depend on it. */
-int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups);
-/* Reserve `cus` compute units for the eigen-solve side streams (CU-masked HIP streams); the
- * streaming kernels then use the remaining ones.  -1 = auto (default), 0 = no partition.  Call before
- * the first batch. */
-int32_t swk_set_eig_cus(swk_ctx *ctx, int32_t cus);
 /* G^(-1/2) of the n x n Gram matrix: 0 = coupled Newton-Schulz on the f64 matrix cores (default; falls back
  * to Jacobi by itself if it does not converge), 1 = cyclic Jacobi eigen-solve. */
 int32_t swk_set_eig_method(swk_ctx *ctx, int32_t method);

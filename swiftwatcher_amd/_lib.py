@@ -129,8 +129,6 @@ _SIGS = {
     "swk_prof_window_iters": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "swk_set_ialm_variant": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_pass_tuning": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
-    "swk_set_ialm_groups": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
-    "swk_set_eig_cus": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_eig_method": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
 }
 EXPORTS = sorted(_SIGS)
@@ -359,12 +357,6 @@ class Context:
         v = ctypes.c_int64(0)
         self._check(self._lib.swk_prof_redo_batches(self._h, ctypes.byref(v)))
         return v.value
-
-    def set_ialm_groups(self, groups):
-        self._check(self._lib.swk_set_ialm_groups(self._h, int(groups)))
-
-    def set_eig_cus(self, cus):
-        self._check(self._lib.swk_set_eig_cus(self._h, int(cus)))
 
     def set_eig_method(self, method):
         self._check(self._lib.swk_set_eig_method(self._h, int(method)))

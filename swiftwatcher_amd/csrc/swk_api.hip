@@ -25,7 +25,6 @@ enum Slot {
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
-constexpr int kMaxGroups = 8;
 
 }  // namespace
 
@@ -58,14 +57,8 @@ struct swk_ctx {
     unsigned long long pass_b16 = 0;   // sum over windows of IalmWin::pass_b16 since the last swk_prof_reset
     double norm_spec = 256.0;      // M-state pass: ||Z|| every other iteration while above 256 x tol (<= 0: every iteration)
     int sparse_backoff = 0, norm_backoff = 0;   // batches for which a guess stays off after it failed (same video, same behaviour)
-    int ialm_groups = 0;                 // 0 = auto
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
-    int eig_cus = -1;                    // CUs reserved for the eigen-solve side streams (-1 auto, 0 none)
-    int num_cus = 0;
-    bool stream_masked = false;
-    hipStream_t gstream[8] = {nullptr};  // side streams of the IALM window groups
-    hipEvent_t ev_pass[8] = {nullptr}, ev_small[8] = {nullptr}, ev_poll[8][2] = {{nullptr}};
-    int ngroups_ready = 0;
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};   // the host polls convergence two iterations late (run_ialm)
     IalmWin *last_win = nullptr;         // per-window IALM state of the last run
     int last_nwin = 0;
     int64_t pstride = 0;                 // plane pitch of the A/Y/E workspaces of the last IALM run
@@ -146,43 +139,10 @@ struct Timed {
     }
 };
 
-// CU partition: the streaming kernels fill every CU they may use (two 256-thread blocks each take a
-// whole CU's registers), so a one-workgroup eigen-solve launched next to them would have to wait for
-// a CU to drain.  With eig_cus > 0 the main stream is confined to the first (num_cus - eig_cus) CUs and
-// the side streams to the last eig_cus, and both kinds of kernels always find room.
-void cu_mask(const swk_ctx *ctx, bool side, uint32_t *mask, int words)
+int ensure_poll_events(swk_ctx *ctx)
 {
-    for (int i = 0; i < words; ++i) mask[i] = 0;
-    const int split = ctx->num_cus - ctx->eig_cus;
-    for (int cu = 0; cu < ctx->num_cus; ++cu)
-        if ((cu >= split) == side) mask[cu >> 5] |= 1u << (cu & 31);
-}
-
-int ensure_groups(swk_ctx *ctx, int ngroups)
-{
-    const int words = (ctx->num_cus + 31) / 32;
-    uint32_t mask[32];
-    if (ctx->eig_cus > 0 && !ctx->stream_masked) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        hipStream_t ns;
-        cu_mask(ctx, false, mask, words);
-        HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ns, words, mask));
-        (void)hipStreamDestroy(ctx->stream);
-        ctx->stream = ns;
-        ctx->stream_masked = true;
-    }
-    for (int g = ctx->ngroups_ready; g < ngroups; ++g) {
-        if (ctx->eig_cus > 0) {
-            cu_mask(ctx, true, mask, words);
-            HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->gstream[g], words, mask));
-        } else
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream[g], hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pass[g], hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_small[g], hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_poll[g][0], hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_poll[g][1], hipEventDisableTiming));
-        ctx->ngroups_ready = g + 1;
-    }
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->ev_poll[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming));
     return SWK_OK;
 }
 
@@ -199,7 +159,6 @@ void drain_prof(swk_ctx *ctx)
 
 int sync(swk_ctx *ctx)
 {
-    for (int g = 0; g < ctx->ngroups_ready; ++g) HIPCHK(ctx, hipStreamSynchronize(ctx->gstream[g]));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     if (const int le = g_launch_error.exchange(0)) {          // a launcher could not set a kernel attribute or start a kernel
@@ -274,13 +233,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     if (variant >= 4 && variant != 6 && (want_A || want_E)) variant = 2;
     if (wide) variant = 6;
     const bool mstate = variant == 4 || variant == 5;          // the M-state pass (ialm_mstate.hip), with / without the software pipeline
-    // auto: one group.  With the Newton-Schulz solver (~0.15 ms per window on one CU) the small-matrix
-    // kernel is ~3 % of a step and overlapping it no longer pays; groups > 1 (+ swk_set_eig_cus) remain for
-    // the Jacobi method (swk_set_eig_method(1)), whose ~1 ms solves are worth hiding.
-    int ngroups = ctx->ialm_groups > 0 ? ctx->ialm_groups : 1;
-    if (ngroups > kMaxGroups) ngroups = kMaxGroups;
-    if (ngroups > nwin) ngroups = nwin;
-    b.nblk = ialm_pass_nblk(variant, n, P, (nwin + ngroups - 1) / ngroups);   // blocks per window, sized per launch
+    b.nblk = ialm_pass_nblk(variant, n, P, nwin);   // blocks per window, sized per launch
     b.nred = b.nblk > 4 ? 1 : b.nblk;       // several slabs: reduce them chip-wide first (k_gram_reduce)
     b.pstride = ((int64_t)P + 127) & ~(int64_t)127;      // whole groups of 8 tiles
     b.fpad = mstate ? ialm_mstate_fpad(n) : (n + 15) & ~15;
@@ -325,100 +278,44 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     }
     if (want_E) HIPCHK(ctx, hipMemsetAsync(b.E, 0, felems * 8, s));
 
-    // Window groups.  The eigen-solve of a window runs on ONE compute unit for about a millisecond;
-    // a streaming pass over a group of windows takes about as long on the whole chip.  So the batch is
-    // cut into groups: all streaming passes go back to back on the main stream, each group's
-    // small-matrix kernel goes on the group's side stream, and events tie pass_g(k) -> small_g(k) ->
-    // pass_g(k+1).  While group g solves its eigenproblems the chip streams the other groups.
-    if (ctx->eig_cus < 0) {          // auto partition, decided once, at the first batch
-        int e = (ngroups > 1 && ctx->eig_method == 1) ? (nwin + ngroups - 1) / ngroups : 0;
-        if (e > 32) e = 32;
-        if (e > 0 && e < 8) e = 8;
-        ctx->eig_cus = e;
-    }
-    int rc = ensure_groups(ctx, ngroups);
+    // One chain on the context's stream: start, then per iteration pass -> (slab sum) -> small-matrix step.  (Rounds 1 / 2 cut the
+    // batch into window groups whose eigen-solves ran on CU-masked side streams beside the other groups' passes; with the
+    // Newton-Schulz solver the small-matrix kernel is ~3 % of a step and the overlap stopped paying: removed in round 3.)
+    int rc = ensure_poll_events(ctx);
     if (rc) return rc;
-    struct Group { IalmBuffers b; int w0; bool finished; };
-    Group grp[kMaxGroups];
-    for (int g = 0; g < ngroups; ++g) {
-        const int w0 = (int)((int64_t)nwin * g / ngroups), w1 = (int)((int64_t)nwin * (g + 1) / ngroups);
-        Group &gr = grp[g];
-        gr.w0 = w0; gr.finished = false;
-        gr.b = b;
-        gr.b.nwin = w1 - w0;
-        gr.b.X = b.X + (size_t)w0 * n * P;
-        gr.b.S = b.S + (size_t)w0 * n * P;
-        gr.b.A = b.A + (size_t)w0 * b.fpad * b.pstride;
-        gr.b.Y = b.Y + (size_t)w0 * b.fpad * b.pstride;
-        gr.b.U = b.U ? b.U + (size_t)w0 * b.fpad * b.pstride : nullptr;
-        gr.b.Salt = b.Salt ? b.Salt + (size_t)w0 * n * P : nullptr;
-        gr.b.E = b.E ? b.E + (size_t)w0 * b.fpad * b.pstride : nullptr;
-        gr.b.Bm = b.Bm + (size_t)w0 * n * n;
-        gr.b.Vprev = b.Vprev + (size_t)w0 * n * n;
-        gr.b.gpart = b.gpart + (size_t)w0 * b.nblk * n * n;
-        gr.b.zzpart = b.zzpart + (size_t)w0 * b.nblk;
-        gr.b.win = b.win + w0;
-        gr.b.active = b.active + g;
-    }
     const int check_from = 6;     // no window converges earlier (mu grows 1.5x per iteration)
-    for (int g = 0; g < ngroups; ++g) {
-        // window statistics (||X||_F, max) and, for the M-state pass, the first Gram matrix in the same read of X
-        // on the integer matrix cores; windows it does not cover get the f64 start pass below
-        grp[g].b.use_gram8 = (mstate && ctx->use_gram8 && gram_u8_supported(grp[g].b)) ? 1 : 0;
-        { Timed t(ctx, SWK_K_IALM_STATS);
-          if (grp[g].b.use_gram8) launch_gram_u8(s, grp[g].b); else launch_ialm_stats(s, grp[g].b);
-          launch_ialm_init(s, grp[g].b, lmbda); }
-        // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
-        // SWK_K_IALM_PASS times only the full 33 B/element streaming passes
-        { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, grp[g].b, 0, variant, 0, ctx->pass_tune); }
-        // one group: everything in order on the main stream (no cross-stream events: a lone window's iteration is a
-        // chain of three short kernels, and every event hop costs microseconds of it)
-        hipStream_t gs0 = ngroups == 1 ? s : ctx->gstream[g];
-        if (ngroups > 1) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
-            HIPCHK(ctx, hipStreamWaitEvent(gs0, ctx->ev_pass[g], 0));
-        }
-        { Timed t(ctx, SWK_K_IALM_SMALL, gs0);
-          if (grp[g].b.nblk > 4) launch_gram_reduce(gs0, grp[g].b);
-          if (variant == 6) launch_ialm_small_wide(gs0, grp[g].b, 0, lmbda, tol, maxiter, wide_work + (size_t)grp[g].w0 * ialm_small_wide_doubles(n));
-          else launch_ialm_small(gs0, grp[g].b, 0, lmbda, tol, maxiter, ctx->eig_method); }
-        if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs0));
-    }
+    // window statistics (||X||_F, max) and, for the M-state pass, the first Gram matrix in the same read of X
+    // on the integer matrix cores; windows it does not cover get the f64 start pass below
+    b.use_gram8 = (mstate && ctx->use_gram8 && gram_u8_supported(b)) ? 1 : 0;
+    { Timed t(ctx, SWK_K_IALM_STATS);
+      if (b.use_gram8) launch_gram_u8(s, b); else launch_ialm_stats(s, b);
+      launch_ialm_init(s, b, lmbda); }
+    // the Gram-only start pass reads X alone (1 B/element): booked with the statistics family so
+    // SWK_K_IALM_PASS times only the full streaming passes
+    { Timed t(ctx, SWK_K_IALM_STATS); launch_ialm_pass(s, b, 0, variant, 0, ctx->pass_tune); }
+    auto small_step = [&](int k) {
+        Timed t(ctx, SWK_K_IALM_SMALL);
+        if (b.nblk > 4) launch_gram_reduce(s, b);
+        if (variant == 6) launch_ialm_small_wide(s, b, k, lmbda, tol, maxiter, wide_work);
+        else launch_ialm_small(s, b, k, lmbda, tol, maxiter, ctx->eig_method);
+    };
+    small_step(0);
     for (int k = 1; k <= maxiter + 2; ++k) {
-        bool any = false;
-        for (int g = 0; g < ngroups; ++g) {
-            Group &gr = grp[g];
-            if (gr.finished) continue;
-            // convergence is polled two iterations late so the host never stalls the queues; the
-            // launches made meanwhile for an already finished group return at their first branch
-            const int kc = k - 2;
-            if (kc >= check_from) {
-                HIPCHK(ctx, hipEventSynchronize(ctx->ev_poll[g][kc & 1]));
-                if (ctx->h_active[g * 2 + (kc & 1)] <= 0) { gr.finished = true; continue; }
-            }
-            if (k > maxiter) { gr.finished = true; continue; }
-            any = true;
-            if (ngroups > 1) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
-            { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, gr.b, k == 1 ? 1 : 2, variant, k, ctx->pass_tune); }
-            hipStream_t gs = ngroups == 1 ? s : ctx->gstream[g];
-            if (ngroups > 1) {
-                HIPCHK(ctx, hipEventRecord(ctx->ev_pass[g], s));
-                HIPCHK(ctx, hipStreamWaitEvent(gs, ctx->ev_pass[g], 0));
-            }
-            { Timed t(ctx, SWK_K_IALM_SMALL, gs);
-              if (gr.b.nblk > 4) launch_gram_reduce(gs, gr.b);
-              if (variant == 6) launch_ialm_small_wide(gs, gr.b, k, lmbda, tol, maxiter, wide_work + (size_t)gr.w0 * ialm_small_wide_doubles(n));
-              else launch_ialm_small(gs, gr.b, k, lmbda, tol, maxiter, ctx->eig_method); }
-            if (ngroups > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_small[g], gs));
-            if (k >= check_from) {
-                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[g * 2 + (k & 1)], gr.b.active, sizeof(int), hipMemcpyDeviceToHost, gs));
-                HIPCHK(ctx, hipEventRecord(ctx->ev_poll[g][k & 1], gs));
-            }
+        // convergence is polled two iterations late so the host never stalls the queue; the launches made
+        // meanwhile for an already finished batch return at their first branch
+        const int kc = k - 2;
+        if (kc >= check_from) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev_poll[kc & 1]));
+            if (ctx->h_active[kc & 1] <= 0) break;
         }
-        if (!any) break;
+        if (k > maxiter) break;
+        { Timed t(ctx, SWK_K_IALM_PASS); launch_ialm_pass(s, b, k == 1 ? 1 : 2, variant, k, ctx->pass_tune); }
+        small_step(k);
+        if (k >= check_from) {
+            HIPCHK(ctx, hipMemcpyAsync(&ctx->h_active[k & 1], b.active, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_poll[k & 1], s));
+        }
     }
-    // everything after the IALM runs on the main stream: join the side streams
-    if (ngroups > 1) for (int g = 0; g < ngroups; ++g) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_small[g], 0));
     if (mstate) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
     if (mstate && (b.spec > 0.0 || b.nspec > 0.0 || b.guard > 0.0)) {
         // did any window stop right after a pass that had its sparse-image stores switched off?
@@ -559,7 +456,6 @@ int32_t swk_ctx_create(int32_t device, int32_t max_windows, int32_t max_n, int32
     if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SWK_ERR_HIP; }
     swk_ctx *ctx = new swk_ctx();
     ctx->device = device;
-    ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_active, 256, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "stream / pinned memory creation failed";
@@ -591,12 +487,8 @@ void swk_ctx_destroy(swk_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_prof(ctx);
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
-    for (int g = 0; g < ctx->ngroups_ready; ++g) {
-        (void)hipStreamSynchronize(ctx->gstream[g]);
-        (void)hipEventDestroy(ctx->ev_pass[g]); (void)hipEventDestroy(ctx->ev_small[g]);
-        (void)hipEventDestroy(ctx->ev_poll[g][0]); (void)hipEventDestroy(ctx->ev_poll[g][1]);
-        (void)hipStreamDestroy(ctx->gstream[g]);
-    }
+    for (int i = 0; i < 2; ++i)
+        if (ctx->ev_poll[i]) (void)hipEventDestroy(ctx->ev_poll[i]);
     for (int i = 0; i < SL_COUNT; ++i)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
@@ -750,25 +642,10 @@ int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)
     return SWK_OK;
 }
 
-int32_t swk_set_ialm_groups(swk_ctx *ctx, int32_t groups)
-{
-    if (!ctx || groups < 0 || groups > kMaxGroups) return SWK_ERR_ARG;
-    ctx->ialm_groups = groups;
-    return SWK_OK;
-}
-
 int32_t swk_set_eig_method(swk_ctx *ctx, int32_t method)
 {
     if (!ctx || method < 0 || method > 1) return SWK_ERR_ARG;
     ctx->eig_method = method;
-    return SWK_OK;
-}
-
-int32_t swk_set_eig_cus(swk_ctx *ctx, int32_t cus)
-{
-    if (!ctx || cus < -1 || cus > 128) return SWK_ERR_ARG;
-    if (ctx->ngroups_ready > 0 || ctx->stream_masked) return fail(ctx, SWK_ERR_ARG, "swk_set_eig_cus must be called before the first batch");
-    ctx->eig_cus = cus;
     return SWK_OK;
 }
 

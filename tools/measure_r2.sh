@@ -39,7 +39,7 @@ TMO=300 step bench_p3 python3 bench.py --no-cpu-baseline --no-classify --size P3
 TMO=300 step bench_p3_n21 python3 bench.py --no-cpu-baseline --size P3 --n 21 --windows 96
 TMO=300 step bench_nofind python3 bench.py --no-cpu-baseline --no-cudnn-benchmark
 TMO=300 step bench_overlap python3 bench.py --no-cpu-baseline --overlap --steps 4
-TMO=300 step bench_groups2 python3 bench.py --no-cpu-baseline --no-classify --groups 2
+# (round 2 also ran --groups 2 here: window groups on CU-masked side streams, removed in round 3)
 TMO=300 step bench_classifier python3 tools/bench_classifier.py
 TMO=300 step bench_framequeue python3 tools/bench_framequeue.py
 TMO=300 step bench_pipeline python3 tools/bench_pipeline.py
