@@ -22,6 +22,20 @@ namespace swk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kSmallThreads = 1024;
+
+// Diagnostic build (tools/small_stamp.sh, -DSWK_SMALL_STAMP): window 0's thread 0 leaves the 100 MHz wall clock at the phase
+// boundaries of every launch (row = iteration k); swk_small_stamp_read copies the table out.  Not part of libswk.so.
+#ifdef SWK_SMALL_STAMP
+__device__ long long g_small_stamp[64][10];          // 0..6 wall clock at the phase boundaries, 8 / 9 shader clock around the solver loop
+#define SWK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && k < 64) g_small_stamp[k][i] = wall_clock64(); } while (0)
+#define SWK_STAMP_CYC(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && k < 64) g_small_stamp[k][i] = clock64(); } while (0)
+__device__ long long g_ns_stamp[64][8];          // shader clock inside solver step 3 of every launch
+#define SWK_STAMP_NS(i) do { if (it == 3 && threadIdx.x == 0 && blockIdx.x == 0 && k < 64) g_ns_stamp[k][i] = clock64(); } while (0)
+#else
+#define SWK_STAMP_NS(i) do { } while (0)
+#define SWK_STAMP_CYC(i) do { } while (0)
+#define SWK_STAMP(i) do { } while (0)
+#endif
 constexpr int kJac = 65;              // LDS row pitch of the Jacobi matrices
 
 __device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, int &q)
@@ -29,6 +43,51 @@ __device__ __forceinline__ void round_robin_pair(int m, int r, int k, int &p, in
     if (k == 0) { p = m - 1; q = r; }
     else { p = (r + k) % (m - 1); q = (r - k + (m - 1)) % (m - 1); }
     if (p > q) { int tmp = p; p = q; q = tmp; }
+}
+
+// Sum over the 64 lanes of a wave by DPP moves (quad permutes, row shifts, row broadcasts: register-file operations) instead of six
+// dependent trips through the LDS crossbar (__shfl: 625 cycles of a solver step, tools/small_stamp.py); every lane gets the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xf, false);
+    // lanes without a source (row shifts at a row's start, rows masked out) read +0.0
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = dpp_add<0xb1, 0xf>(v);          // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);          // quad_perm:[2,3,0,1]: every lane holds its quad's sum
+    v = dpp_add<0x114, 0xf>(v);         // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);         // row_shr:8: lanes 12..15 of a row hold the row's sum
+    v = dpp_add<0x142, 0xa>(v);         // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);         // row_bcast:31 into rows 2, 3: lane 63 holds the wave's sum
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// v of lane `index` (uniform), for every lane
+__device__ __forceinline__ double lane_value(double v, int index)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)bits, index), hi = __builtin_amdgcn_readlane((int)(bits >> 32), index);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// Sum over the workgroup, the waves' sums added in wave order (reproducible); every thread gets it.  red: one double per wave.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();                                             // an earlier sum may still be being read
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double total = 0.0;
+    for (int i = 0; i < nwaves; ++i) total += red[i];
+    return total;
 }
 
 // Convergence test and scalar update.  Returns false when the window is (now) finished.
@@ -45,15 +104,10 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
     if (k >= 1) {
         double acc = 0.0;
         for (int i = tid; i < nblk; i += nthreads) acc += b.zzpart[(int64_t)w * nblk + i];
-        red[tid] = acc;
-        __syncthreads();
-        for (int s = nthreads / 2; s; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
+        const double zz = block_sum(acc, red);
         // a pass that read all of U_{k-1} delivers ||Z_k||^2; one that read only frames 0..3 of it (IalmWin::ru == 0)
         // delivers the sum over those frames: a LOWER bound
-        const double ratio = sqrt(red[0]) / dnorm;               // :297
+        const double ratio = sqrt(zz) / dnorm;                   // :297
         if (tid == 0) {
             // bookkeeping for the roofline: what pass k had to move per element (M-state pass; 1/16-byte units):
             // X 1 + M 8 written (+ 8 read after the first pass) + U 2 or 2/16 each way + the sparse image if stored
@@ -230,7 +284,10 @@ __device__ void jacobi_invsqrt(double *G, double *V, double *Wout, int n, double
 // PITCH = NPAD + 2 makes the A reads conflict-free (16 rows land 4 banks apart) and the B reads 2-way.
 // Result: lane l, component r <-> element (16ti + (l>>4) + 4r, 16tj + (l&15)).
 // ---------------------------------------------------------------------------------
-template <int NPAD, int PITCH>
+// KS = k-steps that hold live frames (ceil(n / 4) rounded up to even, a template parameter of the kernel): rows and columns from 4 KS
+// on are dead directions whose only entries are the unit diagonal, so for a live output element the steps beyond contribute exact
+// zeros and are left out (the CLI's queue of 21 frames: 6 of 8).
+template <int PITCH, int KS>
 __device__ __forceinline__ d4 mm_tile(const double *L, const double *R, int ti, int tj, int lane)
 {
     // two accumulator chains (even / odd k-steps): a dependent f64 MFMA waits out the previous one's latency
@@ -238,11 +295,11 @@ __device__ __forceinline__ d4 mm_tile(const double *L, const double *R, int ti, 
     const int lo = lane & 15, hi = lane >> 4;
     const double *lp = L + (16 * ti + lo) * PITCH + hi;
     const double *rp = R + hi * PITCH + 16 * tj + lo;
-    double a[NPAD / 4], bb[NPAD / 4];
+    double a[KS], bb[KS];
 #pragma unroll
-    for (int kk = 0; kk < NPAD / 4; ++kk) { a[kk] = lp[4 * kk]; bb[kk] = rp[4 * kk * PITCH]; }
+    for (int kk = 0; kk < KS; ++kk) { a[kk] = lp[4 * kk]; bb[kk] = rp[4 * kk * PITCH]; }
 #pragma unroll
-    for (int kk = 0; kk < NPAD / 4; kk += 2) {
+    for (int kk = 0; kk < KS; kk += 2) {
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bb[kk], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk + 1], bb[kk + 1], acc1, 0, 0, 0);
     }
@@ -257,6 +314,11 @@ __device__ __forceinline__ void store_tile(double *M, d4 v, int ti, int tj, int 
     for (int r = 0; r < 4; ++r) M[(16 * ti + (lane >> 4) + 4 * r) * PITCH + col] = v[r];
 }
 
+// Coefficients of the scaled Newton-Schulz steps (see the kernel): the sequence depends on nothing but the starting bound lo = 1e-3, so
+// the host forms it once (IEEE sqrt and division, as the kernel did per step and thread: 430 cycles of a step) and passes it by value.
+constexpr int kNsScaled = 12;
+struct NsSteps { double ta[kNsScaled], tc[kNsScaled]; int count; };          // count = steps until the tracked bound reaches 1 (10)
+
 template <int NB> struct NsCfg {
     static constexpr int NPAD = 16 * NB;
     static constexpr int PITCH = NPAD + 2;
@@ -267,21 +329,27 @@ template <int NB> struct NsCfg {
     static constexpr size_t lds_bytes = doubles * sizeof(double) + 128 * sizeof(int);   // pq[32], flag, dead[64]
 };
 
-template <int NB>
-__global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter, int method)
+template <int NB, int KS>
+__global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int k, double lmbda, double tol, int maxiter, int method, NsSteps steps)
 {
     using C = NsCfg<NB>;
     constexpr int NPAD = C::NPAD, PITCH = C::PITCH, NT = C::NT;
     extern __shared__ double sm[];
     double *Y = sm, *Z = sm + C::mat, *T = sm + 2 * C::mat;
+    // up to 48 frames a second pair of matrices fits (inside the Jacobi fallback's space): a solver step writes its Y T, T Z there and
+    // the pairs change roles -- one barrier per step less than overwriting in place
+    constexpr bool DB = 5 * C::mat <= C::jac;
+    double *Yn = DB ? sm + 3 * C::mat : Y, *Zn = DB ? sm + 4 * C::mat : Z;
     double *red = sm + (3 * C::mat > C::jac ? 3 * C::mat : C::jac);        // [1024]
     double2 *cs = (double2 *)(red + kSmallThreads);                           // [32]
     double *wgt = red + kSmallThreads + 64;                                   // [64]
     int *ints = (int *)(wgt + kMaxN);                                         // pq[32], flag, sweeps, dead mask...
-    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nthreads = blockDim.x;      // 256 threads for n <= 32, else 1024
+    const int w = blockIdx.x, tid = threadIdx.x, n = b.n, nthreads = blockDim.x;      // 256 threads for n <= 16, 512 for n <= 32, else 1024
     const int lane = tid & 63, wave = tid >> 6;
     IalmScal cur;
+    SWK_STAMP(0);
     if (!small_prologue(b, w, k, lmbda, tol, maxiter, red, cur)) return;
+    SWK_STAMP(1);
     double *Bm = b.Bm + (int64_t)w * n * n;
     IalmWin &st = b.win[w];
 
@@ -293,18 +361,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         __syncthreads();
         gram_reduce(b, w, Y, PITCH, k);
         __syncthreads();
+        SWK_STAMP(2);
         // s = ||G||_F (fixed-order reduction)
         double acc = 0.0;
         for (int idx = tid; idx < n * n; idx += nthreads) { const double v = Y[(idx / n) * PITCH + idx % n]; acc += v * v; }
-        red[tid] = acc;
-        __syncthreads();
-        for (int s = nthreads / 2; s; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
-        const double sc = sqrt(red[0]) * (1.0 + 1e-12);
+        const double sc = sqrt(block_sum(acc, red)) * (1.0 + 1e-12);
         const double inv_sc = 1.0 / sc;
-        __syncthreads();
         if (tid < NPAD) ints[40 + tid] = (tid >= n || Y[tid * PITCH + tid] == 0.0) ? 1 : 0;      // dead directions
         __syncthreads();
         for (int idx = tid; idx < NPAD * NPAD; idx += nthreads) {
@@ -315,6 +377,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         }
         __syncthreads();
         bool final_step = false, converged = false;
+        SWK_STAMP(3);
+        SWK_STAMP_CYC(8);
         // Scaled Newton-Schulz: with the singular values x = sqrt(eig(ZY)) known to lie in [lo, 1], the step
         // x <- x (3 alpha / 2 - alpha^3 x^2 / 2), alpha = sqrt(3 / (1 + lo + lo^2)), maps [lo, 1] onto [p(lo), 1] with
         // p(lo) = p(1): small values grow 2.6x per step instead of 1.5x.  Any x in (0, 1] stays in (0, 1] for any
@@ -322,52 +386,73 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         // lo starts at 1e-3, i.e. cond(G) up to 1e6 relative to ||G||_F.
         // Once ||I - ZY||_F < 1/2 (every x above 0.7) the plain step takes over: it converges quadratically from there
         // and the stopping rule below counts plain steps.
-        double lo = n == 1 ? 1.0 : 1e-3, prev_res2 = 1e300;
+        // (The bound is tracked by the recurrence lo <- lo (3 alpha / 2 - alpha^3 lo^2 / 2): it depends on nothing but its start, so the
+        // host hands the coefficients of its ten steps over as a table, NsSteps.)
+        double prev_res2 = 1e300;
+        bool plain = n == 1;
+        // lane i keeps the coefficients of scaled step i (read back with a lane index: no memory access inside the loop)
+        const double my_ta = lane < kNsScaled ? steps.ta[lane] : 1.5, my_tc = lane < kNsScaled ? steps.tc[lane] : 0.5;
+        // this wave's tile of Z Y (phase 1) never changes: which of the lane's four elements sit in a dead row or column
+        const int pt = wave < NT ? wave : 0, pti = pt / NB, ptj = pt - pti * NB;
+        int deadm = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (ints[40 + 16 * pti + (lane >> 4) + 4 * r] | ints[40 + 16 * ptj + (lane & 15)]) deadm |= 1 << r;
         for (int it = 0; it < 60; ++it) {
-            if (prev_res2 < 0.25) lo = 1.0;
-            const double alpha = lo < 0.9999 ? sqrt(3.0 / (1.0 + lo + lo * lo)) : 1.0;
-            const double ta = 1.5 * alpha, tc = 0.5 * alpha * alpha * alpha;
-            lo = lo < 0.9999 ? lo * (ta - tc * lo * lo) : 1.0;
+            SWK_STAMP_NS(0);
+            if (prev_res2 < 0.25) plain = true;
+            const bool unit = plain || it >= steps.count;          // alpha == 1: the plain step
+            const double ta = unit ? 1.5 : lane_value(my_ta, it), tc = unit ? 0.5 : lane_value(my_tc, it);
             // phase 1: P = Z Y;  T = ta I - tc P  (= (3I - P)/2 once alpha = 1);  residual ||I - P||_F^2
             double r2 = 0.0;
-            for (int t = wave; t < NT; t += nthreads / 64) {
-                const int ti = t / NB, tj = t - ti * NB;
-                d4 p = mm_tile<NPAD, PITCH>(Z, Y, ti, tj, lane);
+            SWK_STAMP_NS(1);
+            if (wave < NT) {
+                d4 p = mm_tile<PITCH, KS>(Z, Y, pti, ptj, lane);
                 d4 tt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                    const int row = 16 * pti + (lane >> 4) + 4 * r, col = 16 * ptj + (lane & 15);
                     const double id = row == col ? 1.0 : 0.0;
                     const double e = id - p[r];
-                    r2 += e * e;
-                    // dead directions (zero rows/columns of G) are decoupled 1x1 blocks held at 1
-                    const bool dead = ints[40 + row] || ints[40 + col];
-                    tt[r] = dead ? id : (alpha == 1.0 ? id + 0.5 * e : ta * id - tc * p[r]);   // (3I - P)/2 = I + (I - P)/2
+                    // dead directions (zero rows/columns of G) are decoupled 1x1 blocks held at 1 (up to 4 KS; beyond, the
+                    // skipped k-steps leave them 0: they never enter a live element, and they stay out of the residual)
+                    const bool dead = (deadm >> r) & 1;
+                    r2 += dead ? 0.0 : e * e;
+                    tt[r] = dead ? id : (unit ? id + 0.5 * e : ta * id - tc * p[r]);   // (3I - P)/2 = I + (I - P)/2
                 }
-                store_tile<PITCH>(T, tt, ti, tj, lane);
+                store_tile<PITCH>(T, tt, pti, ptj, lane);
             }
-            for (int off = 32; off; off >>= 1) r2 += __shfl_down(r2, off);
+            SWK_STAMP_NS(2);
+            r2 = wave_sum(r2);
             if (lane == 0) red[wave] = r2;
+            SWK_STAMP_NS(3);
             __syncthreads();
             double res2 = 0.0;
             for (int i = 0; i < nthreads / 64; ++i) res2 += red[i];
+            SWK_STAMP_NS(4);
             // phase 2: Y T and T Z into registers (both read the old Y, Z), then write back
             d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
             const int j0 = wave, j1 = wave + nthreads / 64;
             const int t0 = j0 % NT, t1 = j1 % NT;
             const int ti0 = t0 / NB, tj0 = t0 - ti0 * NB, ti1 = t1 / NB, tj1 = t1 - ti1 * NB;
-            if (j0 < 2 * NT) o0 = j0 < NT ? mm_tile<NPAD, PITCH>(Y, T, ti0, tj0, lane) : mm_tile<NPAD, PITCH>(T, Z, ti0, tj0, lane);
-            if (j1 < 2 * NT) o1 = j1 < NT ? mm_tile<NPAD, PITCH>(Y, T, ti1, tj1, lane) : mm_tile<NPAD, PITCH>(T, Z, ti1, tj1, lane);
+            if (j0 < 2 * NT) o0 = j0 < NT ? mm_tile<PITCH, KS>(Y, T, ti0, tj0, lane) : mm_tile<PITCH, KS>(T, Z, ti0, tj0, lane);
+            if (j1 < 2 * NT) o1 = j1 < NT ? mm_tile<PITCH, KS>(Y, T, ti1, tj1, lane) : mm_tile<PITCH, KS>(T, Z, ti1, tj1, lane);
+            SWK_STAMP_NS(5);
+            if (!DB) __syncthreads();
+            SWK_STAMP_NS(6);
+            if (j0 < 2 * NT) store_tile<PITCH>(j0 < NT ? Yn : Zn, o0, ti0, tj0, lane);
+            if (j1 < 2 * NT) store_tile<PITCH>(j1 < NT ? Yn : Zn, o1, ti1, tj1, lane);
             __syncthreads();
-            if (j0 < 2 * NT) store_tile<PITCH>(j0 < NT ? Y : Z, o0, ti0, tj0, lane);
-            if (j1 < 2 * NT) store_tile<PITCH>(j1 < NT ? Y : Z, o1, ti1, tj1, lane);
-            __syncthreads();
+            if (DB) { double *t_ = Y; Y = Yn; Yn = t_; t_ = Z; Z = Zn; Zn = t_; }
+            SWK_STAMP_NS(7);
             ns_iters = it + 1;
             if (!(res2 == res2)) break;                                      // NaN: give up, Jacobi decides
             prev_res2 = res2;
             if (final_step) { converged = true; break; }
-            if (res2 < 1e-8 && alpha == 1.0) final_step = true;              // ||I - ZY|| < 1e-4: two more plain steps reach 1e-16
+            if (res2 < 1e-8 && unit) final_step = true;              // ||I - ZY|| < 1e-4: two more plain steps reach 1e-16
         }
+        SWK_STAMP_CYC(9);
+        SWK_STAMP(4);
         if (converged) {
             // A (numerically) zero eigenvalue that is not a zero row of G -- the duplicated last frame of every video
             // (io_video.py:51-53) makes two columns of M equal -- converges here to a weight of 1e6 and more on a
@@ -376,16 +461,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             // behaviour for zero singular directions).
             double zacc = 0.0;
             for (int idx = tid; idx < n * n; idx += nthreads) { const double v = Z[(idx / n) * PITCH + idx % n]; zacc += v * v; }
-            __syncthreads();
-            red[tid] = zacc;
-            __syncthreads();
-            for (int s = nthreads / 2; s; s >>= 1) {
-                if (tid < s) red[tid] += red[tid + s];
-                __syncthreads();
-            }
-            if (!(red[0] < 1e11)) converged = false;
-            __syncthreads();
+            if (!(block_sum(zacc, red) < 1e11)) converged = false;
         }
+        SWK_STAMP(5);
         if (converged) {
             const double wscale = 1.0 / sqrt(sc);
             for (int idx = tid; idx < n * n; idx += nthreads) {
@@ -395,6 +473,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
                 Bm[idx] = (i == j ? 1.0 : 0.0) - cur.inv_mu * wv;
             }
             if (tid == 0) st.sweeps = ns_iters;
+            SWK_STAMP(6);
             return;
         }
         need_jacobi = true;
@@ -489,14 +568,43 @@ void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
     hipLaunchKernelGGL(k_gram_reduce, dim3((b.n * b.n + 63) / 64, b.nwin), dim3(1024), 0, s, b);
 }
 
+static NsSteps ns_steps()
+{
+    NsSteps t{};
+    double lo = 1e-3;
+    t.count = 0;
+    for (int i = 0; i < kNsScaled; ++i) {
+        double alpha = 1.0;
+        if (lo < 0.9999) {
+            alpha = sqrt(3.0 / (1.0 + lo + lo * lo));
+            t.count = i + 1;
+        }
+        t.ta[i] = 1.5 * alpha;
+        t.tc[i] = 0.5 * alpha * alpha * alpha;
+        lo = lo < 0.9999 ? lo * (t.ta[i] - t.tc[i] * lo * lo) : 1.0;
+    }
+    return t;
+}
+
+template <int NB, int KS>
+static void launch_small_ks(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
+{
+    static unsigned long long attr_mask = 0;
+    static const NsSteps steps = ns_steps();
+    if (!ensure_dyn_lds((const void *)k_ialm_small<NB, KS>, NsCfg<NB>::lds_bytes, attr_mask)) return;
+    // up to 32 frames the matrices are 2 x 2 tiles: eight waves take the eight products Y T, T Z of a step one each (two per SIMD, so
+    // that one's matrix instructions run under the other's operand reads) without idling eight more at every barrier; one tile: four
+    hipLaunchKernelGGL((k_ialm_small<NB, KS>), dim3(b.nwin), dim3(NB == 1 ? 256 : NB == 2 ? 512 : kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda,
+                       tol, maxiter, method, steps);
+    note_launch();
+}
+
 template <int NB>
 static void launch_small_nb(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
 {
-    static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_ialm_small<NB>, NsCfg<NB>::lds_bytes, attr_mask)) return;
-    // up to 32 frames the matrices are 2 x 2 tiles: four waves do them without idling twelve more at every barrier
-    hipLaunchKernelGGL((k_ialm_small<NB>), dim3(b.nwin), dim3(NB <= 2 ? 256 : kSmallThreads), NsCfg<NB>::lds_bytes, s, b, k, lmbda, tol, maxiter, method);
-    note_launch();
+    // k-steps that hold live frames, rounded up to even: 4 NB, or two fewer when the last eight rows of the padded matrix are empty
+    if (b.n <= 16 * NB - 8) launch_small_ks<NB, 4 * NB - 2>(s, b, k, lmbda, tol, maxiter, method);
+    else launch_small_ks<NB, 4 * NB>(s, b, k, lmbda, tol, maxiter, method);
 }
 
 void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, int method)
@@ -510,3 +618,16 @@ void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda,
 }
 
 }  // namespace swk
+
+#ifdef SWK_SMALL_STAMP
+#pragma GCC visibility push(default)
+extern "C" int32_t swk_small_stamp_read(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(swk::g_small_stamp), sizeof(swk::g_small_stamp)) == hipSuccess ? 0 : -1;
+}
+extern "C" int32_t swk_ns_stamp_read(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(swk::g_ns_stamp), sizeof(swk::g_ns_stamp)) == hipSuccess ? 0 : -1;
+}
+#pragma GCC visibility pop
+#endif
