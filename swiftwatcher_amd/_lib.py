@@ -363,8 +363,13 @@ class Context:
 
     # ---- hot path ----
     def batch_run_raw(self, inp, params, out):
-        self.generation += 1
-        self._check(self._lib.swk_batch_run(self._h, ctypes.byref(inp), ctypes.byref(params), ctypes.byref(out)))
+        """swk_batch_run.  Returns the batch's generation: the value Context.generation has while what this batch left on the device
+        is still there (another thread's batch may already have moved it on by the time the caller looks at the attribute)."""
+        with self._lock:
+            self.generation += 1
+            generation = self.generation
+            self._check(self._lib.swk_batch_run(self._h, ctypes.byref(inp), ctypes.byref(params), ctypes.byref(out)))
+        return generation
 
     def batch_run(self, frames, nwin, n, crop=None, params=None, stages=STAGES, want_A=False, want_E=False, seg_cap=255,
                   device_stages=False, reverse_frames=False):
@@ -373,7 +378,7 @@ class Context:
         frames: u8 array (nwin*n, H, W, 3) or (nwin*n, H, W), C-contiguous in the last two/three axes
         crop:   (x0, y0, Wc, Hc) inside each frame, or None for the whole frame
         Returns dict with the requested stage stacks (nwin*n, Hc, Wc) u8, 'iters' (nwin,),
-        'nseg' (nwin*n,), 'segs' structured array (nwin*n, seg_cap), optionally 'A'/'E' (nwin, P, n).
+        'nseg' (nwin*n,), 'segs' structured array (nwin*n, seg_cap), 'generation' (see batch_run_raw), optionally 'A'/'E' (nwin, P, n).
         device_stages=True: the stage stacks stay on the GPU -- res['planes'] is a DevicePlanes whose read(stage, frame)
         copies one image to the host when somebody asks for it (swk_output.planes_on_device).
         reverse_frames=True: frame j of the batch is frames[F - 1 - j] (negative frame stride): a window that lies in memory in
@@ -419,7 +424,7 @@ class Context:
         out.iters = res["iters"].ctypes.data
         out.nseg = res["nseg"].ctypes.data
         out.segs = res["segs"].ctypes.data
-        self.batch_run_raw(inp, params, out)
+        res["generation"] = self.batch_run_raw(inp, params, out)          # for swk_segment_inputs_last (segment_inputs_last)
         return res
 
     # ---- stage-level entry points ----

@@ -357,7 +357,7 @@ class FrameQueue(deque):
         stages = tuple(STAGE_KEYS) if self.keep_stages else ()
         res = ctx.batch_run(stack, 1, n, crop=(rx, ry, Wc, Hc), params=self.params, stages=stages, device_stages=True,
                             reverse_frames=backwards)
-        generation = ctx.generation
+        generation = res["generation"]
         self.last_iters = int(res["iters"][0])
         nseg = res["nseg"]
         if np.any(nseg > res["segs"].shape[1]):
@@ -454,7 +454,7 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     nseg = res["nseg"]
     if np.any(nseg > res["segs"].shape[1]):
         raise _lib.SwkError("more regions in a frame than seg_cap")
-    batch = WindowBatch(ctx, ctx.generation, int(nseg.sum()), min_seg_size, queue=owner) if stack.ndim == 4 else None
+    batch = WindowBatch(ctx, res["generation"], int(nseg.sum()), min_seg_size, queue=owner) if stack.ndim == 4 else None
     if batch is not None and classifier is not None:
         batch.launch(classifier)
     if info is not None:

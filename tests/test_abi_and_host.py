@@ -230,3 +230,43 @@ def test_host_staging_helpers(built_lib):
         _lib.cut_boxes(frames, frame_of, bad)
     empty_buf, empty_offs = _lib.cut_boxes(frames, np.zeros(0, np.int32), np.zeros((0, 4), np.int32))
     assert empty_buf.size == 0 and empty_offs.size == 0
+
+
+def test_a_batch_learns_its_own_generation_under_the_context_lock():
+    """Two threads run batches on one Context (a reader that segments ahead beside the loop's own segment_queue): each must get the
+    generation of ITS batch, or swk_segment_inputs_last is later asked about the other thread's frames (seen once on the GPU box as
+    '*total does not match the batch').  The library call is replaced by a slow stub; no GPU."""
+    import threading
+    import time
+    from swiftwatcher_amd import _lib
+
+    class SlowLib:
+        def __init__(self):
+            self.running = 0
+            self.overlap = False
+
+        def swk_batch_run(self, *args):
+            self.running += 1
+            self.overlap |= self.running > 1
+            time.sleep(0.05)
+            self.running -= 1
+            return 0
+
+    ctx = object.__new__(_lib.Context)
+    ctx._lock = threading.RLock()
+    ctx._lib = SlowLib()
+    ctx._h = None
+    ctx.generation = 0
+    got = []
+
+    def run():
+        g = ctx.batch_run_raw(_lib.Input(), _lib.Params(), _lib.Output())
+        got.append((g, ctx.generation))          # (the attribute may already belong to another thread's batch)
+
+    threads = [threading.Thread(target=run) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(g for g, _ in got) == [1, 2, 3, 4] and not ctx._lib.overlap
+    ctx._h = None
