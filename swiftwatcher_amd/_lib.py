@@ -253,29 +253,36 @@ class Context:
         return out
 
     def staging(self, shape):
-        """A page-locked uint8 staging array of this shape, kept for the next call with the same shape (calls on a context are
-        synchronous: the upload out of it has finished when batch_run returns)."""
-        cache = self.__dict__.setdefault("_staging", {})
-        arr = cache.get(shape)
-        if arr is None:
-            if len(cache) >= 2:
-                cache.pop(next(iter(cache)))
-            arr = cache[shape] = pinned_empty(shape, np.uint8, device=self.device)
+        """A page-locked uint8 staging array of this shape, kept for the calling thread's next call with the same shape (calls on a
+        context are synchronous: the upload out of it has finished when batch_run returns; a thread that segments ahead and the
+        loop's own thread never share one)."""
+        key = (threading.get_ident(), tuple(shape))
+        with self._lock:
+            cache = self.__dict__.setdefault("_staging", {})
+            arr = cache.get(key)
+            if arr is None:
+                if len(cache) >= 3:
+                    cache.pop(next(iter(cache)))          # (an evicted array lives on while its user holds it)
+                arr = cache[key] = pinned_empty(shape, np.uint8, device=self.device)
         return arr
 
     def take_planes(self, nbytes):
         """A device buffer of nbytes from the context's free list (or a new one): see DevicePlanes."""
-        free = self._plane_pool.get(nbytes)
-        return free.pop() if free else self.device_alloc(nbytes)
+        with self._lock:
+            free = self._plane_pool.get(nbytes)
+            if free:
+                return free.pop()
+        return self.device_alloc(nbytes)
 
     def give_planes(self, ptr, nbytes, keep=4):
         if not getattr(self, "_h", None):
             return
-        free = self._plane_pool.setdefault(nbytes, [])
-        if len(free) < keep:
-            free.append(ptr)
-        else:
-            self.device_free(ptr)
+        with self._lock:
+            free = self._plane_pool.setdefault(nbytes, [])
+            if len(free) < keep:
+                free.append(ptr)
+                return
+        self.device_free(ptr)
 
     def __del__(self):
         try:

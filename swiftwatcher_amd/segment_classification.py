@@ -14,6 +14,7 @@ Differences from the reference, all deliberate:
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -502,6 +503,7 @@ class SegmentClassifier:
         # device-side input buffers of scores_from_device / predict_last_batch: two slots, each with the event of the last forward
         # that read it (a slot is handed to the library's stream again only after that event)
         self._slots = None
+        self._lock = threading.RLock()          # one scoring at a time (see _scores_device)
         self._graphs = {}
         self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
         self._graph_error = None
@@ -599,7 +601,7 @@ class SegmentClassifier:
             self._events = []
         return ms, rows, calls
 
-    def scores(self, segment_images):
+    def _scores_unlocked(self, segment_images):
         out = []
         for i in range(0, len(segment_images), self.batch_size):
             chunk = segment_images[i:i + self.batch_size]
@@ -620,8 +622,19 @@ class SegmentClassifier:
             self._slots = (key, xb, fb, [None, None])
         return self._slots[1:]
 
-    @torch.no_grad()
+    def scores(self, segment_images):
+        with self._lock:
+            return self._scores_unlocked(segment_images)
+
     def _scores_device(self, cut):
+        """_scores_device_unlocked under the classifier's lock: the input slots, their events, the captured graphs and the forward's
+        buffers belong to the classifier, and two threads score through one classifier when a reader segments (and scores) ahead
+        beside the counting loop (io_frames.PresegmentingReader, pipeline.py windows_per_call): one scoring at a time."""
+        with self._lock:
+            return self._scores_device_unlocked(cut)
+
+    @torch.no_grad()
+    def _scores_device_unlocked(self, cut):
         """Scores of a device-resident batch.  cut(net_ptr, frame_ptr, net_cap, first, pad, channels_last) -> (total, skipped) writes
         the network inputs of segments [first, first + net_cap) (a library call: its own stream, synchronous).  Two input slots: the
         library cuts and resamples chunk i + 1 while PyTorch's stream runs the network on chunk i; a slot is written again only after
