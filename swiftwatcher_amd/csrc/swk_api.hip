@@ -364,7 +364,10 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
 {
     const int nwin = ctx->last_nwin;
     std::vector<IalmWin> hw(nwin);
-    HIPCHK(ctx, hipMemcpy(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost));
+    // (on the context's own, non-blocking stream: a copy on the null stream would wait for every blocking stream of the process, and
+    //  fails outright while another thread captures a HIP graph on one -- the classifier does, segment_classification.py)
+    HIPCHK(ctx, hipMemcpyAsync(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int32_t> it(nwin);
     ctx->last_int_start = 0;
     ctx->last_eig_sweeps = 0;
@@ -374,7 +377,10 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
         if (hw[w].sweeps > ctx->last_eig_sweeps) ctx->last_eig_sweeps = hw[w].sweeps;
     }
     if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
-    if (d_iters) HIPCHK(ctx, hipMemcpy(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice));
+    if (d_iters) {
+        HIPCHK(ctx, hipMemcpyAsync(d_iters, it.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // `it` is a local
+    }
     return SWK_OK;
 }
 

@@ -563,7 +563,9 @@ class SegmentClassifier:
                 self._forward(x)                                            # kernel attributes, persistent tiles, library handles
                 torch.cuda.current_stream(self.device).synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread-local capture mode: another thread may be inside the library meanwhile (a reader that segments ahead:
+                # stream synchronisations, allocations) -- under the default, global mode those calls fail while this one captures
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     # (two halves on two streams inside the graph -- forwards on disjoint rows of the persistent tiles, row0 --
                     # were measured: 3.11 against 3.17 ms per window of the counting loop, no gain; one chain it is)
                     out = self._forward(x)

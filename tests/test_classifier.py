@@ -704,3 +704,61 @@ def test_fused_maxpool_squeeze_kernel_against_torch():
                                                            8, 8, 16, 0, 0) != 0          # cin not a multiple of 32
     assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 23, 96, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
                                                            11, 11, 16, 0, 0) != 0        # 121 pooled pixels: more than three pixel tiles
+
+
+@pytest.mark.gpu
+def test_two_threads_share_a_context_and_a_classifier(tmp_path):
+    """A reader that segments and scores ahead (io_frames.PresegmentingReader, pipeline.py windows_per_call) works beside the counting
+    loop's own FrameQueue on ONE context and ONE classifier.  Two threads, each with its own clip, hammer both at once: every
+    window's kept boxes must equal what the same thread's clip gives when it runs alone.  (What this guards: a batch taking another
+    thread's generation -- 'total does not match the batch', seen once on the GPU box -- shared staging arrays, interleaved use of the
+    classifier's input slots.)"""
+    import threading
+    from swiftwatcher_amd import synthetic
+    from swiftwatcher_amd.data_structures import FrameQueue
+    crop_region = [(40, 30), (40 + 212, 30 + 106)]
+    n, windows = 21, 6
+    clips = [synthetic.full_frames(70 + c, n * windows, crop_region, frame_hw=(180, 300), birds=8 + 3 * c, bird_len=(14, 24),
+                                   bird_wid=(6, 10))[::-1].copy() for c in range(2)]
+
+    def crops_of(clip):
+        q = FrameQueue()
+        out = []
+        q.push_list_of_frames([clip[i] for i in range(n)], list(range(n)), ["t"] * n)
+        q.preprocess_queue(crop_region, None)
+        q.segment_queue((24, 24), crop_region)
+        while not q.is_empty():
+            out.extend(s.segment_image for s in q.pop_frame().segments)
+        return out
+    clf, _, _ = _calibrated_classifier(crops_of(clips[0]) + crops_of(clips[1]), 9, tmp_path, margin=1e-4)
+
+    def run(clip, result, errors):
+        try:
+            q = FrameQueue()
+            for w in range(windows):
+                q.push_list_of_frames([clip[w * n + i] for i in range(n)], list(range(w * n, w * n + n)), ["t"] * n)
+                q.preprocess_queue(crop_region, None)
+                q.segment_queue((24, 24), crop_region)
+                while not q.is_empty():
+                    f = q.pop_frame()
+                    result.append((f.frame_number, [s.bbox for s in f.segments], [s.bbox for s in clf(f.segments)]))
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    alone = []
+    for clip in clips:
+        res, err = [], []
+        run(clip, res, err)
+        assert not err, err
+        alone.append(res)
+    assert all(sum(len(k) for _, _, k in res) > 20 for res in alone)
+    for rep in range(2):
+        together, errors = [[], []], []
+        threads = [threading.Thread(target=run, args=(clips[c], together[c], errors)) for c in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert together[0] == alone[0] and together[1] == alone[1]
+    assert clf._graph_error is None, clf._graph_error          # no HIP-graph capture was broken by the other thread's library calls
