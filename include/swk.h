@@ -17,8 +17,10 @@
  *   - "mem" fields say where a caller buffer lives: SWK_MEM_HOST (pageable or pinned
  *     host memory; the library copies) or SWK_MEM_DEVICE (a HIP device pointer on the
  *     context's GPU, e.g. torch.Tensor.data_ptr()).
- *   - one swk_ctx per process per GPU; a context is not thread-safe; calls are
- *     synchronous (work runs on the context's own HIP stream and is waited for).
+ *   - one swk_ctx per process per GPU; a context is not thread-safe (serialise the calls on it: the Python layer holds one
+ *     lock per context); calls are synchronous (work runs on the context's own non-blocking HIP stream and is waited for;
+ *     the library issues nothing on the null stream, so it can run beside a thread that captures a HIP graph in
+ *     thread-local capture mode).
  *   - there is NO CPU fallback: without a usable gfx950 device swk_ctx_create fails
  *     with SWK_ERR_NOGPU and nothing else can be called.
  */
