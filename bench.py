@@ -246,6 +246,15 @@ def reference_call_pattern(ctx_device, clf, args, geo):
     loop = {}
 
     def run_loop(make_reader, classifier, **kw):
+        # a side measurement must never take the headline line down with it: a failure is reported in its place
+        try:
+            return run_loop_(make_reader, classifier, **kw)
+        except Exception as exc:          # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return {"error": repr(exc)}
+
+    def run_loop_(make_reader, classifier, **kw):
         events = pipeline.swift_counting_algorithm(make_reader(1), crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
         del events
         gc.collect()
@@ -271,7 +280,8 @@ def reference_call_pattern(ctx_device, clf, args, geo):
         loop["roi_stream"] = run_loop(stream, clf)
         loop["roi_stream_windows_per_call_8"] = run_loop(stream, clf, windows_per_call=8)
         loop["roi_stream_presegmenting_reader_8"] = run_loop(lambda c: PresegmentingReader(stream(c), queue_size=n, windows=8, device=ctx_device), clf)
-        loop["roi_stream"]["input_mb_per_frame"] = round(os.path.getsize(paths[1]) / len(flist) / 1e6, 3)
+        if "error" not in loop["roi_stream"]:
+            loop["roi_stream"]["input_mb_per_frame"] = round(os.path.getsize(paths[1]) / len(flist) / 1e6, 3)
     out["count_loop"] = dict(loop["reference_pattern"], roi_stream=loop["roi_stream"],
                              roi_stream_windows_per_call_8=loop["roi_stream_windows_per_call_8"],
                              presegmenting_reader_8=loop["presegmenting_reader_8"],
@@ -608,9 +618,20 @@ def main():
                                      "value": round(hw_ * n / dt_h, 1), "unit": "frames/s", "input_gb_per_s": round(hw_ * n * P * 3 / dt_h / 1e9, 2)}
             del host
             if args.size == "P2":
-                res.update(reference_call_pattern(local, clf, args, geo))
+                try:
+                    res.update(reference_call_pattern(local, clf, args, geo))
+                except Exception as exc:          # noqa: BLE001  (sub-results only: the line above them stands)
+                    import traceback
+                    traceback.print_exc()
+                    res["drop_in"] = res.get("drop_in", {"error": repr(exc)})
+                    res["count_loop"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:          # the CPU baseline is a single-GPU-run companion (rank 0 at N = 1 only)
-            res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
+            try:
+                res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
+            except Exception as exc:          # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                res["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
