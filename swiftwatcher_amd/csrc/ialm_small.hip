@@ -316,8 +316,15 @@ __device__ __forceinline__ void store_tile(double *M, d4 v, int ti, int tj, int 
 
 // Coefficients of the scaled Newton-Schulz steps (see the kernel): the sequence depends on nothing but the starting bound lo = 1e-3, so
 // the host forms it once (IEEE sqrt and division, as the kernel did per step and thread: 430 cycles of a step) and passes it by value.
-constexpr int kNsScaled = 12;
-struct NsSteps { double ta[kNsScaled], tc[kNsScaled]; int count; };          // count = steps until the tracked bound reaches 1 (10)
+// A window's Gram matrix moves little from one IALM iteration to the next, and the last solve leaves ||Z||_F^2 = sum_i 1 / x_i^2 behind:
+// sqrt(n) / ||Z||_F is the scale of the small singular values, half of it the next solve's starting bound -- the table whose start lies
+// at or below that is used (kNsStarts of them; 12 solver steps from 1e-3 become 8 to 11).
+constexpr int kNsScaled = 12, kNsStarts = 6;
+struct NsSteps {
+    double start[kNsStarts];                                   // the starting bounds, ascending; start[0] = 1e-3 serves a first solve
+    double ta[kNsStarts][kNsScaled], tc[kNsStarts][kNsScaled];
+    int count[kNsStarts];                                      // steps until the tracked bound reaches 1
+};
 
 template <int NB> struct NsCfg {
     static constexpr int NPAD = 16 * NB;
@@ -383,15 +390,25 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         // x <- x (3 alpha / 2 - alpha^3 x^2 / 2), alpha = sqrt(3 / (1 + lo + lo^2)), maps [lo, 1] onto [p(lo), 1] with
         // p(lo) = p(1): small values grow 2.6x per step instead of 1.5x.  Any x in (0, 1] stays in (0, 1] for any
         // alpha in [1, sqrt 3], so a wrong guess for lo only costs speed; as lo -> 1 the step is the plain one.
-        // lo starts at 1e-3, i.e. cond(G) up to 1e6 relative to ||G||_F.
+        // lo starts at 1e-3 for a window's first solve, i.e. cond(G) up to 1e6 relative to ||G||_F, later where the last solve's
+        // ||Z||_F puts it (NsSteps).
         // Once ||I - ZY||_F < 1/2 (every x above 0.7) the plain step takes over: it converges quadratically from there
         // and the stopping rule below counts plain steps.
         // (The bound is tracked by the recurrence lo <- lo (3 alpha / 2 - alpha^3 lo^2 / 2): it depends on nothing but its start, so the
-        // host hands the coefficients of its ten steps over as a table, NsSteps.)
+        // host hands the coefficients of its steps over as tables, one per starting bound: NsSteps.)
         double prev_res2 = 1e300;
         bool plain = n == 1;
-        // lane i keeps the coefficients of scaled step i (read back with a lane index: no memory access inside the loop)
-        const double my_ta = lane < kNsScaled ? steps.ta[lane] : 1.5, my_tc = lane < kNsScaled ? steps.tc[lane] : 0.5;
+        // the table this solve runs on (uniform), then lane i keeps the coefficients of its scaled step i (read back with a lane
+        // index: no memory access inside the loop)
+        int tab = 0;
+        {
+            const double zf2 = st.zf2;
+            const double guess = zf2 > 0.0 ? 0.5 * sqrt((double)n / zf2) : 0.0;
+#pragma unroll
+            for (int i = 1; i < kNsStarts; ++i) tab = guess >= steps.start[i] ? i : tab;
+        }
+        const int nscaled = steps.count[tab];
+        const double my_ta = lane < kNsScaled ? steps.ta[tab][lane] : 1.5, my_tc = lane < kNsScaled ? steps.tc[tab][lane] : 0.5;
         // this wave's tile of Z Y (phase 1) never changes: which of the lane's four elements sit in a dead row or column
         const int pt = wave < NT ? wave : 0, pti = pt / NB, ptj = pt - pti * NB;
         int deadm = 0;
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
         for (int it = 0; it < 60; ++it) {
             SWK_STAMP_NS(0);
             if (prev_res2 < 0.25) plain = true;
-            const bool unit = plain || it >= steps.count;          // alpha == 1: the plain step
+            const bool unit = plain || it >= nscaled;          // alpha == 1: the plain step
             const double ta = unit ? 1.5 : lane_value(my_ta, it), tc = unit ? 0.5 : lane_value(my_tc, it);
             // phase 1: P = Z Y;  T = ta I - tc P  (= (3I - P)/2 once alpha = 1);  residual ||I - P||_F^2
             double r2 = 0.0;
@@ -461,7 +478,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_small(IalmBuffers b, int
             // behaviour for zero singular directions).
             double zacc = 0.0;
             for (int idx = tid; idx < n * n; idx += nthreads) { const double v = Z[(idx / n) * PITCH + idx % n]; zacc += v * v; }
-            if (!(block_sum(zacc, red) < 1e11)) converged = false;
+            const double zf2 = block_sum(zacc, red);
+            if (!(zf2 < 1e11)) converged = false;
+            else if (tid == 0) st.zf2 = zf2;
         }
         SWK_STAMP(5);
         if (converged) {
@@ -571,17 +590,20 @@ void launch_gram_reduce(hipStream_t s, const IalmBuffers &b)
 static NsSteps ns_steps()
 {
     NsSteps t{};
-    double lo = 1e-3;
-    t.count = 0;
-    for (int i = 0; i < kNsScaled; ++i) {
-        double alpha = 1.0;
-        if (lo < 0.9999) {
-            alpha = sqrt(3.0 / (1.0 + lo + lo * lo));
-            t.count = i + 1;
+    const double starts[kNsStarts] = {1e-3, 2.5e-3, 6e-3, 1.5e-2, 4e-2, 1e-1};
+    for (int j = 0; j < kNsStarts; ++j) {
+        double lo = t.start[j] = starts[j];
+        t.count[j] = 0;
+        for (int i = 0; i < kNsScaled; ++i) {
+            double alpha = 1.0;
+            if (lo < 0.9999) {
+                alpha = sqrt(3.0 / (1.0 + lo + lo * lo));
+                t.count[j] = i + 1;
+            }
+            t.ta[j][i] = 1.5 * alpha;
+            t.tc[j][i] = 0.5 * alpha * alpha * alpha;
+            lo = lo < 0.9999 ? lo * (t.ta[j][i] - t.tc[j][i] * lo * lo) : 1.0;
         }
-        t.ta[i] = 1.5 * alpha;
-        t.tc[i] = 0.5 * alpha * alpha * alpha;
-        lo = lo < 0.9999 ? lo * (t.ta[i] - t.tc[i] * lo * lo) : 1.0;
     }
     return t;
 }

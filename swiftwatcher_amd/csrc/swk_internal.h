@@ -73,6 +73,7 @@ struct IalmWin {
     double last_ratio;             // last full ||Z||_F / ||X||_F that was formed
     int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
     unsigned long long pass_b16;   // algorithmic bytes per element moved by the passes 1..iter of this window, in 1/16 B
+    double zf2;                    // ||(G/s)^(-1/2)||_F^2 of the last Newton-Schulz solve (0: none yet): where the next solve's bound starts
 };
 
 struct IalmBuffers {
