@@ -1,16 +1,17 @@
-// The small-matrix step of every IALM iteration, one workgroup (1024 threads) per window:
+// The small-matrix step of every IALM iteration, one workgroup per window (256 / 512 / 1024 threads for up to 16 / 32 / 64 frames):
 // convergence test (image_filtering.py:297), mu <- 1.5 mu (:295), reduction of the per-block Gram
 // partials, W = G^(-1/2) of the n x n Gram matrix, B = I - W/mu for the next streaming pass.
 //
 // G^(-1/2) by the coupled Newton-Schulz iteration
 //     Y0 = G/s, Z0 = I;   T = (3I - Z Y)/2;   Y <- Y T,  Z <- T Z;      Z -> (G/s)^(-1/2)
 // (s = ||G||_F >= lambda_max, so every eigenvalue of Y0 lies in (0, 1] and the iteration converges,
-// x2.25 per step for the small ones, then quadratically).  It is nothing but 64x64x64 matrix products:
+// x2.25 per step for the small ones -- x6.8 with the scaled steps described in the kernel -- then quadratically).  It is nothing
+// but 64x64x64 matrix products (the k-steps that hold live frames: template parameter KS):
 // v_mfma_f64_16x16x4_f64 on operands in LDS.  The iterates are polynomials in G (symmetric, commuting)
 // only in exact arithmetic, and the iteration is stable only as long as the rounding errors stay of the
 // form a true product leaves: mirroring the upper triangle, or reading the left operand transposed
 // (both tried: cheaper, and both diverge once cond(G) is large), is not allowed -- every product is the
-// full NPAD x NPAD matrix product in the written order.  12-25 iterations of 3 products.
+// full NPAD x NPAD matrix product in the written order.  8-12 steps of 3 products (tools/small_stamp.py times their parts).
 // Zero rows of G (all-zero "null" frames, io_video.py:40-44) are decoupled by construction, iterate
 // as a unit diagonal, and get weight 0 at the end (null frames are excluded).
 // If the iteration has not reached the quadratic regime after 60 steps (numerically singular G) the
