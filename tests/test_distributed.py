@@ -33,9 +33,10 @@ def _worker(rank, world, port, n_videos, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_videos", [5, 2, 1])
-def test_two_ranks_shard_and_gather(n_videos):
-    world = 2
+@pytest.mark.parametrize("world,n_videos", [(2, 5), (2, 2), (2, 1), (4, 4), (4, 6)])
+def test_ranks_shard_and_gather(world, n_videos):
+    """Videos round-robin over the ranks, one gather of the per-video counts (BASELINE config 4 is 4 videos on 4 GPUs; config 5's
+    8-GPU leg the same with more ranks): gloo on the CPU, the same code path RCCL takes."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -51,7 +52,7 @@ def test_two_ranks_shard_and_gather(n_videos):
     for rank, calls, table, t in out:
         assert calls == list(range(rank, n_videos, world))      # round-robin shard, no overlap
         assert table == expect                                    # identical full table on every rank
-        assert t == 2.0                                           # max over ranks
+        assert t == float(world)                                  # max over ranks
 
 
 def test_single_process_without_group():
