@@ -30,10 +30,16 @@ __global__ __launch_bounds__(512, 4) void k_conv7x7s2_relu(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     float *lbias = lds + ((4 * KR * 2 * PITCH + 3) & ~3);
     // ---- weights: W[co][c][dy][dx] -> lds[((dyl * 21 + 3 dx + c) * 2 + half) * PITCH + co], patch row dy = dyl + 4 half (row 7: zeros) ----
-    for (int i = tid; i < 4 * KR * 2 * NP; i += 512) {
-        const int co = i % NP, k = i / NP, half = k & 1, kk = k >> 1, dyl = kk / KR, j = kk - dyl * KR, dx = j / 3, c = j - 3 * dx;
-        const int dy = dyl + 4 * half;
-        lds[k * PITCH + co] = dy < 7 ? wgt[((co * 3 + c) * 7 + dy) * 7 + dx] : 0.0f;
+    //      (walked in W's own order: consecutive lanes read consecutive floats; walked in LDS order the reads were a gather with a
+    //      stride of 147 floats, 64 lines per instruction -- a third of a window-sized forward's conv1 time)
+    for (int i = tid; i < NP * 147; i += 512) {
+        const int co = i / 147, rem = i - co * 147, c = rem / 49, r2 = rem - c * 49, dy = r2 / 7, dx = r2 - dy * 7;
+        const int half = dy >> 2, dyl = dy & 3;
+        lds[((dyl * KR + 3 * dx + c) * 2 + half) * PITCH + co] = wgt[i];
+    }
+    for (int i = tid; i < KR * NP; i += 512) {          // patch row 7 (half 1, dyl 3): zeros
+        const int j = i / NP, co = i - j * NP;
+        lds[((3 * KR + j) * 2 + 1) * PITCH + co] = 0.0f;
     }
     if (tid < NP) lbias[tid] = bias[tid];
     __syncthreads();

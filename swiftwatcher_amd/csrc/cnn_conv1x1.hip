@@ -69,11 +69,15 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__
 #pragma unroll
             for (int v = 0; v < NV; ++v) a[d][v] = *(const float4 *)(p + KC * d + 4 * v);
     }
-    // ---- weights, transposed: coalesced along ci in W[co][ci], conflict-free in LDS ----
-    for (int i = tid; i < cin * NP; i += NT) {
-        const int co = i / cin, ci = i - co * cin;
-        lds[ci * PITCH + co] = co < cout ? wgt[(int64_t)co * cin + ci] : 0.0f;
-    }
+    // ---- weights, transposed: W[co][ci] read along ci as float4s (16 lanes = 64 channels of one output channel), [ci][co] in LDS.
+    //      No index arithmetic beyond shifts: with `i / cin` per element the staging cost a window-sized forward a few microseconds
+    //      per workgroup and kernel (cin is a runtime value: a 32-bit division is some forty instructions) ----
+    for (int co = tid >> 4; co < NP; co += NT / 16)
+        for (int c4 = (tid & 15) * 4; c4 < cin; c4 += 64) {
+            const float4 wv = co < cout ? *(const float4 *)(wgt + (int64_t)co * cin + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float *q = lds + c4 * PITCH + co;
+            q[0] = wv.x; q[PITCH] = wv.y; q[2 * PITCH] = wv.z; q[3 * PITCH] = wv.w;
+        }
     for (int i = tid; i < NP; i += NT) lbias[i] = i < cout ? bias[i] : 0.0f;
     __syncthreads();
 
@@ -219,7 +223,7 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     if (!src || !weight || !bias || !dst || n < 1 || h < 1 || w < 1 || cin < 16 || (cin & 15) || cin > 1024 || cout < 4 || cout > 256 ||
         (cout & 3) || (dC & 3) || (c_off & 3) || (((uintptr_t)dst) & 15) ||
         crop_y < 0 || crop_x < 0 || crop_y + h > sh || crop_x + w > sw || off_y < 0 || off_x < 0 || off_y + h > dH || off_x + w > dW ||
-        c_off < 0 || c_off + cout > dC || (((uintptr_t)src) & 15))
+        c_off < 0 || c_off + cout > dC || ((((uintptr_t)src) | ((uintptr_t)weight)) & 15))
         return SWK_ERR_ARG;
     using namespace swk;
     const int64_t rows = (int64_t)n * h * w;
