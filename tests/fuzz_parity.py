@@ -1,0 +1,100 @@
+"""Randomised differential run of the HIP path against the oracle (GPU box; part of tests/: the oracle is the checker):
+random frames per window (1 .. 64), ROI sizes, bird counts and sizes, noise kinds (Gaussian of several strengths, none, codec-like
+blocks), duplicated last frames and null padding -- per window the iteration count and the six stage images must be identical and the
+region records equal.  Windows hold >= 1.4e5 elements (below about 1.1e5 the reference itself is LAPACK-dependent)
+and <= 1.2e6 (the oracle's SVDs).  Prints one line per mismatch with the seed that reproduces it, and a summary.
+
+    python3 tests/fuzz_parity.py [seconds] [first seed]          (tests/test_fuzz_parity.py runs a fixed dozen of seeds)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from swiftwatcher_amd import _lib, synthetic          # noqa: E402
+from oracle import reference_path as orc              # noqa: E402
+
+
+def make(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 21, 21, 21, 24, 25, 32, 33, 40, 48, 49, 56, 57, 64, 64]))
+    elems = int(rng.integers(140000, 1200000))
+    P = max(elems // n, 24 * 24)
+    Wc = int(rng.integers(24, 600))
+    Hc = max(P // Wc, 8)
+    Wc = max(min(Wc, P // Hc), 8)
+    if n * Hc * Wc < 140000:
+        Hc = 140000 // (n * Wc) + 1
+    kind = str(rng.choice(["gauss", "quiet", "static", "codec"]))
+    sigma = {"gauss": float(rng.choice([1.5, 2.5, 4.0])), "quiet": float(rng.choice([0.1, 0.5])), "static": 0.0, "codec": 1.5}[kind]
+    birds = int(rng.integers(0, 16))
+    roi = synthetic.roi_window(seed, n, Hc, Wc, birds=birds, noise=sigma, bird_len=(6, 22), bird_wid=(3, 10))
+    if kind == "codec":
+        q = int(rng.choice([2, 4]))
+        f = roi.astype(np.float64)
+        hb, wb = Hc // 8 * 8, Wc // 8 * 8
+        blk = f[:, :hb, :wb].reshape(n, hb // 8, 8, wb // 8, 8, 3)
+        blk[...] = 0.5 * blk + 0.5 * blk.mean(axis=(2, 4), keepdims=True)
+        roi = (np.round(f / q) * q).clip(0, 255).astype(np.uint8)
+    tail = str(rng.choice(["none", "none", "dup", "null", "dup+null"])) if n >= 4 else "none"
+    if "null" in tail:
+        k = int(rng.integers(1, max(2, n // 3)))
+        roi[:k] = 0                                   # queue index 0 = newest: the padding sits at the front (io_video.py:40-44)
+        if "dup" in tail and k + 1 < n:
+            roi[k] = roi[k + 1]
+    elif tail == "dup":
+        roi[0] = roi[1]
+    return dict(n=n, Hc=Hc, Wc=Wc, kind=kind, sigma=sigma, birds=birds, tail=tail), np.ascontiguousarray(roi)
+
+
+def check(ctx, seed):
+    """One random window: (config, list of problems)."""
+    cfg, roi = make(seed)
+    n = cfg["n"]
+    res = ctx.batch_run(roi, 1, n)
+    ref = orc.window(roi)
+    gray = ref["gray"].reshape(n, -1).T
+    k_ref = orc.ialm_defined(gray, return_iters=True)[2]
+    problems = []
+    if int(res["iters"][0]) != k_ref:
+        problems.append("iters %d vs %d" % (int(res["iters"][0]), k_ref))
+    for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+        if not np.array_equal(res[key], ref[key]):
+            problems.append("%s: %d pixels" % (key, int((res[key] != ref[key]).sum())))
+    for i in range(n):
+        got = [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"])) for s in res["segs"][i][:res["nseg"][i]]]
+        want = [(int(s["label"]), int(s["bbox"][0]), int(s["bbox"][1]), int(s["bbox"][2]), int(s["bbox"][3]), int(s["area"]))
+                for s in ref["segments"][i]]
+        if got != want:
+            problems.append("segments of frame %d" % i)
+            break
+    return cfg, problems
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    first = seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    ctx = _lib.Context(0)
+    t0 = time.time()
+    done = bad = 0
+    by_kind = {}
+    while time.time() - t0 < budget:
+        cfg, problems = check(ctx, seed)
+        done += 1
+        by_kind[cfg["kind"]] = by_kind.get(cfg["kind"], 0) + 1
+        if problems:
+            bad += 1
+            print("MISMATCH seed %d %s: %s" % (seed, json.dumps(cfg), "; ".join(problems)), flush=True)
+        if done % 20 == 0:
+            print("... %d windows, %d mismatches, %.0f s" % (done, bad, time.time() - t0), flush=True)
+        seed += 1
+    print(json.dumps({"windows": done, "mismatches": bad, "by_kind": by_kind, "guard_windows": ctx.guard_windows, "redo_batches": ctx.redo_batches,
+                      "first_seed": first, "seconds": round(time.time() - t0, 1)}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,18 @@
+"""A fixed dozen of the random windows of tests/fuzz_parity.py (frames per window, ROI shape, noise kind, duplicated / null frames drawn
+from a seed) against the oracle: iteration count, the six stage images, the region records.  The open-ended run is
+`python3 tests/fuzz_parity.py <seconds>`; its result for this round is kept in profiles/."""
+import pytest
+
+
+@pytest.mark.gpu
+def test_random_windows_match_the_oracle():
+    import fuzz_parity
+    from swiftwatcher_amd import _lib
+    ctx = _lib.Context(0)
+    kinds = set()
+    for seed in range(100000, 100012):
+        cfg, problems = fuzz_parity.check(ctx, seed)
+        kinds.add((cfg["kind"], cfg["tail"]))
+        assert not problems, "seed %d %r: %s" % (seed, cfg, "; ".join(problems))
+    assert len(kinds) >= 5
+    ctx.close()
