@@ -51,26 +51,42 @@ def make(seed):
 
 
 def check(ctx, seed):
-    """One random window: (config, list of problems)."""
+    """One random window -- or, every third seed, a batch of two or three windows of one shape in ONE library call (blocks per window,
+    the small-matrix kernel's grid and the integer start are sized per batch): (config, list of problems)."""
     cfg, roi = make(seed)
     n = cfg["n"]
-    res = ctx.batch_run(roi, 1, n)
-    ref = orc.window(roi)
-    gray = ref["gray"].reshape(n, -1).T
-    k_ref = orc.ialm_defined(gray, return_iters=True)[2]
+    rois = [roi]
+    if seed % 3 == 0 and n * cfg["Hc"] * cfg["Wc"] <= 600000:
+        for extra in range(1 + seed % 2):
+            c2, r2 = make(seed + 7919 * (extra + 1))
+            # same shape, other content: the other seed's scene parameters, this seed's geometry
+            rng = np.random.default_rng(seed + 31 * (extra + 1))
+            r2 = synthetic.roi_window(seed + 7919 * (extra + 1), n, cfg["Hc"], cfg["Wc"], birds=int(rng.integers(0, 16)),
+                                      noise=float(rng.choice([0.0, 0.5, 2.5])), bird_len=(6, 22), bird_wid=(3, 10))
+            rois.append(np.ascontiguousarray(r2))
+    nwin = len(rois)
+    cfg["nwin"] = nwin
+    res = ctx.batch_run(np.concatenate(rois), nwin, n)
     problems = []
-    if int(res["iters"][0]) != k_ref:
-        problems.append("iters %d vs %d" % (int(res["iters"][0]), k_ref))
-    for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
-        if not np.array_equal(res[key], ref[key]):
-            problems.append("%s: %d pixels" % (key, int((res[key] != ref[key]).sum())))
-    for i in range(n):
-        got = [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"])) for s in res["segs"][i][:res["nseg"][i]]]
-        want = [(int(s["label"]), int(s["bbox"][0]), int(s["bbox"][1]), int(s["bbox"][2]), int(s["bbox"][3]), int(s["area"]))
-                for s in ref["segments"][i]]
-        if got != want:
-            problems.append("segments of frame %d" % i)
-            break
+    for w, r in enumerate(rois):
+        ref = orc.window(r)
+        gray = ref["gray"].reshape(n, -1).T
+        k_ref = orc.ialm_defined(gray, return_iters=True)[2]
+        tag = "window %d: " % w if nwin > 1 else ""
+        if int(res["iters"][w]) != k_ref:
+            problems.append(tag + "iters %d vs %d" % (int(res["iters"][w]), k_ref))
+        sl = slice(w * n, (w + 1) * n)
+        for key in ("gray", "rpca", "bilateral", "thresh", "opened", "labels"):
+            if not np.array_equal(res[key][sl], ref[key]):
+                problems.append(tag + "%s: %d pixels" % (key, int((res[key][sl] != ref[key]).sum())))
+        for i in range(n):
+            f = w * n + i
+            got = [(int(s["label"]), int(s["r0"]), int(s["c0"]), int(s["r1"]), int(s["c1"]), int(s["area"])) for s in res["segs"][f][:res["nseg"][f]]]
+            want = [(int(s["label"]), int(s["bbox"][0]), int(s["bbox"][1]), int(s["bbox"][2]), int(s["bbox"][3]), int(s["area"]))
+                    for s in ref["segments"][i]]
+            if got != want:
+                problems.append(tag + "segments of frame %d" % i)
+                break
     return cfg, problems
 
 
