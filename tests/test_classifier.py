@@ -762,3 +762,66 @@ def test_two_threads_share_a_context_and_a_classifier(tmp_path):
         assert not errors, errors
         assert together[0] == alone[0] and together[1] == alone[1]
     assert clf._graph_error is None, clf._graph_error          # no HIP-graph capture was broken by the other thread's library calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("roi_at", ["inside", "top_left_corner", "bottom_right_corner"])
+def test_segment_inputs_of_random_boxes_match_the_host_path(roi_at):
+    """swk_segment_inputs on HAND-MADE region records: boxes of every shape (one pixel, a line, the whole ROI), at the ROI's edges and
+    corners, with the ROI inside the frame or in one of its corners (a box that extract_segment_images grows past the frame is clipped
+    there, image_filtering.py:349-366) -- the network inputs must be the host path's, bit for bit (same crops, same Pillow resize)."""
+    from swiftwatcher_amd import _lib
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.segment_classification import IMAGENET_MEAN, IMAGENET_STD
+    rng = np.random.default_rng({"inside": 1, "top_left_corner": 2, "bottom_right_corner": 3}[roi_at])
+    FH, FW, Hc, Wc, F, cap = 150, 260, 90, 170, 6, 24
+    x0, y0 = {"inside": (45, 30), "top_left_corner": (0, 0), "bottom_right_corner": (FW - Wc, FH - Hc)}[roi_at]
+    crop_region = [(x0, y0), (x0 + Wc, y0 + Hc)]
+    frames = rng.integers(0, 256, size=(F, FH, FW, 3), dtype=np.uint8)
+    records = np.zeros((F, cap), _lib.SEGMENT_DTYPE)
+    counts = np.zeros(F, np.int32)
+    for f in range(F):
+        k = int(rng.integers(3, cap + 1))
+        counts[f] = k
+        for i in range(k):
+            kind = int(rng.integers(0, 6))
+            if kind == 0:          # a single pixel, often on the ROI's border
+                r0 = int(rng.choice([0, Hc - 1, rng.integers(0, Hc)])); c0 = int(rng.choice([0, Wc - 1, rng.integers(0, Wc)]))
+                r1, c1 = r0 + 1, c0 + 1
+            elif kind == 1:        # a horizontal line
+                r0 = int(rng.integers(0, Hc)); r1 = r0 + 1; c0 = int(rng.integers(0, Wc - 30)); c1 = int(rng.integers(c0 + 25, Wc + 1))
+            elif kind == 2:        # a vertical line
+                c0 = int(rng.integers(0, Wc)); c1 = c0 + 1; r0 = int(rng.integers(0, Hc - 30)); r1 = int(rng.integers(r0 + 25, Hc + 1))
+            elif kind == 3:        # the whole ROI
+                r0, c0, r1, c1 = 0, 0, Hc, Wc
+            else:                  # anything
+                r0 = int(rng.integers(0, Hc)); r1 = int(rng.integers(r0 + 1, Hc + 1)); c0 = int(rng.integers(0, Wc)); c1 = int(rng.integers(c0 + 1, Wc + 1))
+            records[f, i] = (i + 1, r0, c0, r1, c1, 0, (r1 - r0) * (c1 - c0), 0, 0)
+    imgs, frame_of = [], []
+    for f in range(F):
+        rps = img.regionprops_from_records(records[f, :counts[f]])
+        crops = img.extract_segment_images(rps, frames[f], (24, 24), crop_region)
+        imgs += crops
+        frame_of += [f] * len(crops)
+    assert len({c.shape[:2] for c in imgs}) > 20
+    ctx = _lib.Context(0)
+    dev = torch.device("cuda", 0)
+    dframes = torch.from_numpy(frames).to(dev)
+    segs = torch.from_numpy(records.view(np.uint8).reshape(F, cap, 48)).to(dev)
+    nseg = torch.from_numpy(counts).to(dev)
+    torch.cuda.synchronize()
+    inp = _lib.Input(frames=dframes.data_ptr(), mem=_lib.MEM_DEVICE, channels=3, nwin=1, n=F, Hc=Hc, Wc=Wc, x0=x0, y0=y0,
+                     frame_stride=FH * FW * 3, row_stride=FW * 3)
+    for pad, nhwc in ((100, False), (8, False), (8, True)):
+        side = 24 + 2 * pad
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        x = torch.empty((len(imgs), 3, side, side), dtype=torch.float32, device=dev, memory_format=fmt)
+        fidx = torch.empty((len(imgs),), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        total, skipped = ctx.segment_inputs(inp, (FH, FW), segs.data_ptr(), nseg.data_ptr(), cap, IMAGENET_MEAN, IMAGENET_STD,
+                                            x.data_ptr(), len(imgs), pad=pad, seg_frame_ptr=fidx.data_ptr(), channels_last=nhwc)
+        assert total == len(imgs) and skipped == 0
+        assert fidx.cpu().tolist() == frame_of
+        _, net = ctx.classifier_input(imgs, IMAGENET_MEAN, IMAGENET_STD, pad=pad)
+        np.testing.assert_array_equal(x.cpu().numpy(), net, err_msg="pad %d nhwc %s" % (pad, nhwc))
+    ctx.close()
