@@ -17,7 +17,8 @@ def _clip(total, hw=(120, 200), seed=0):
 CROP = [(40, 30), (160, 90)]
 
 
-@pytest.mark.parametrize("total,n,prefetch", [(52, 21, True), (52, 21, False), (63, 21, True), (10, 21, True), (44, 7, True)])
+@pytest.mark.parametrize("total,n,prefetch", [(52, 21, True), (52, 21, False), (63, 21, True), (10, 21, True), (44, 7, True), (1, 21, True), (21, 21, True),
+                                             (22, 21, False), (43, 21, True)])
 def test_reader_bookkeeping_equals_array_reader(tmp_path, total, n, prefetch):
     clip = _clip(total)
     path = write_roi_stream(str(tmp_path / "clip.swkroi"), clip, CROP, fps=29.97)
