@@ -22,7 +22,9 @@ import swiftwatcher.io_data as dio                  # noqa: E402
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
-def make_stream(seed, n_frames, H=212, W=424, spawn=0.35):
+def make_stream(seed, n_frames, H=212, W=424, spawn=0.35, grid=0, burst=3):
+    """grid > 0: centroids snapped to multiples of `grid` pixels (equal distances: the assignment's tie-breaking decides);
+    burst: most birds that appear in one frame."""
     rng = np.random.default_rng(seed)
     roi = np.zeros((H, W), np.uint8)
     roi[int(H * 0.55):int(H * 0.8), int(W * 0.12):int(W * 0.88)] = 255
@@ -30,7 +32,7 @@ def make_stream(seed, n_frames, H=212, W=424, spawn=0.35):
     frames = []
     for t in range(n_frames):
         if rng.random() < spawn or t == 0:
-            for _ in range(int(rng.integers(1, 4))):
+            for _ in range(int(rng.integers(1, burst + 1))):
                 r, c = rng.uniform(5, H * 0.5), rng.uniform(5, W - 5)
                 if rng.random() < 0.5:                # aims at the chimney mouth
                     tr, tc = rng.uniform(H * 0.6, H * 0.75), rng.uniform(W * 0.2, W * 0.8)
@@ -43,7 +45,10 @@ def make_stream(seed, n_frames, H=212, W=424, spawn=0.35):
         cents = []
         for b in birds:
             jr, jc = rng.normal(0, 0.7, 2)
-            cents.append((float(b[0] + jr), float(b[1] + jc)))
+            cr, cc = float(b[0] + jr), float(b[1] + jc)
+            if grid:
+                cr, cc = float(round(cr / grid) * grid), float(round(cc / grid) * grid)
+            cents.append((cr, cc))
             b[0] += b[2]; b[1] += b[3]; b[4] -= 1
         birds = [b for b in birds if b[4] > 0 and 0 <= b[0] < H and 0 <= b[1] < W]
         cents = [c for c in cents if 0 <= c[0] < H and 0 <= c[1] < W]
@@ -95,8 +100,15 @@ def run_reference(roi, frames, fps=30.0):
 
 
 if __name__ == "__main__":
-    for name, seed, nf in [("tracker_a", 1, 260), ("tracker_b", 2, 400), ("tracker_sparse", 3, 120)]:
-        roi, frames = make_stream(seed, nf, spawn=0.35 if name != "tracker_sparse" else 0.08)
+    # round 3: a crowd (up to eight new birds per frame), centroids on a 4-pixel grid (ties), a long clip
+    cases = [("tracker_a", 1, 260, {}), ("tracker_b", 2, 400, {}), ("tracker_sparse", 3, 120, dict(spawn=0.08)),
+             ("tracker_crowd", 11, 200, dict(spawn=0.8, burst=8)), ("tracker_grid", 12, 300, dict(grid=4, spawn=0.5)),
+             ("tracker_long", 13, 900, dict(spawn=0.3))]
+    only = sys.argv[1:]
+    for name, seed, nf, kw in cases:
+        if only and name not in only:
+            continue
+        roi, frames = make_stream(seed, nf, **kw)
         assigns, out = run_reference(roi, frames)
         counts = np.array([len(f) for f in frames], np.int64)
         flat = np.array([c for f in frames for c in f], np.float64).reshape(-1, 2)
