@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-classify", action="store_true",
                     help="time the image_filtering part only (the headline metric then reads 'segment'); for kernel A/Bs")
     ap.add_argument("--full-network", action="store_true", help="A/B: the full 224x224 forward instead of the receptive-field cropped one")
+    ap.add_argument("--weights", default="auto", choices=["auto", "model_pt", "calibrated"],
+                    help="classifier weights: model.pt's tensors (tests/golden/classifier_model_pt.npz; 'auto' takes them when the file is "
+                         "there) or random-init weights with a head bias calibrated on the stream")
     ap.add_argument("--cls-batch", type=int, default=8192, help="segments per classifier forward (4096: -2.5 %; 12288: +0.4 %)")
     ap.add_argument("--overlap", action="store_true",
                     help="also time the steps as a two-stage pipeline: the image_filtering part of step i+1 (library stream, "
@@ -80,6 +83,12 @@ def parse():
     ap.add_argument("--host-input", action="store_true", help="(default at N = 1) kept for compatibility: pcie_inclusive is part of the line")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in / count_loop / pcie_inclusive sub-results (kernel A/Bs)")
     ap.add_argument("--loop-windows", type=int, default=24, help="21-frame windows of the count_loop clip (1080p frames in host memory: 130 MB each)")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks of --gpus N may take before they are ended")
+    ap.add_argument("--parity-windows", type=int, default=8,
+                    help="21-frame windows at the head of the count_loop clip that also go through the CPU restatement's pipeline (count_oracle)")
+    ap.add_argument("--video-windows", type=int, default=24, help="21-frame windows per video of the video_sharded leg (0 = skip the leg)")
+    ap.add_argument("--videos-per-gpu", type=int, default=1)
+    ap.add_argument("--verify-all-videos", action="store_true", help="video_sharded: rank 0 recounts every video (default: the first and the last)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher rehearsal without any GPU work: the ranks join the process group (SWK_DIST_BACKEND, gloo on CPU-only "
                          "hosts), run the barrier / max-over-ranks clock / count gather around EMPTY steps and print the line with value 0")
@@ -94,20 +103,60 @@ def launch_ranks(args):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), SWK_BENCH_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        out = tempfile.TemporaryFile()
+        err = tempfile.TemporaryFile()
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+    # every child is watched: a rank that dies before it joins the process group would leave the others in init / the barrier for
+    # ever.  The first non-zero exit (or the overall limit) ends the rest -- they are ordinary children of a process that never
+    # touched a GPU, so terminating them is safe -- and every rank's stderr tail is kept.
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = "rank %d exited with code %d" % (bad[0], codes[bad[0]]) if bad else "no result after %d s" % args.launch_timeout
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.2)
+    codes = [p.returncode for p in procs]
+
+    def tail(f, nbytes=4000):
+        f.seek(0, 2)
+        f.seek(max(f.tell() - nbytes, 0))
+        return f.read().decode(errors="replace")
+
+    logs[0][0].seek(0)
+    out0 = logs[0][0].read().decode(errors="replace")
     # rank 0's JSON line and nothing else (a backend may chat on stdout: gloo prints its peer count there)
-    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
-    sys.stdout.write((lines[-1] + "\n") if lines else out.decode())
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if failed is not None or not lines:
+        sys.stderr.write("bench.py launcher: %s\n" % (failed or "rank 0 printed no result line"))
+        for r, (_, err) in enumerate(logs):
+            sys.stderr.write("---- rank %d (exit %s) stderr tail ----\n%s\n" % (r, codes[r], tail(err)))
+    else:
+        sys.stderr.write(tail(logs[0][1]))
+    sys.stdout.write((lines[-1] + "\n") if lines else out0)
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    worst = max(abs(c) for c in codes)
+    return worst if worst else (1 if failed is not None or not lines else 0)
 
 
 def rehearse(args):
@@ -136,7 +185,7 @@ def rehearse(args):
         dist.destroy_process_group()
 
 
-def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
+def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242, sample=None):
     """The CPU oracle (numpy + C restatement of the reference path, + the batch-1 CPU classifier the reference runs)
     on a bounded sample of the same workload.  kind = "port": the reference's own cv2 / torchvision stages cannot run
     anywhere in this image."""
@@ -155,6 +204,8 @@ def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
     results = [orc.window(roi) for roi in rois]
     t_seg = time.perf_counter() - t0
     nseg = sum(len(s) for res in results for s in res["segments"])
+    if sample is not None:          # the same windows then go through the HIP path: the line's "parity" object (sample_parity)
+        sample.update(rois=rois, results=results)
     out = dict(unit="frames/s", cores=int(threads), kind="port")
     t_cls = 0.0
     if classify:
@@ -197,7 +248,72 @@ def cpu_baseline(n, Hc, Wc, nwin, classify, seed=424242):
     return out
 
 
-def reference_call_pattern(ctx_device, clf, args, geo):
+STAGE_IMAGES = ("gray", "rpca", "bilateral", "thresh", "opened", "labels")
+
+
+def sample_parity(ctx, rois, results, n):
+    """Second half of BASELINE.json's metric ("...; swift-count parity vs ref"), kernel level: the cpu_baseline sample's windows --
+    whose right answers the CPU restatement of the reference has just produced -- through swk_batch_run, the call the timed loop makes:
+    iteration count per window, the six stage images and the region records of every frame compared bit for bit.  Outside the timed
+    regions; the CPU side is the checker here, never the thing measured."""
+    import numpy as np
+    nwin = len(rois)
+    res = ctx.batch_run(np.ascontiguousarray(np.concatenate(rois)), nwin, n)
+    bad, per_stage, segments = 0, {k: 0 for k in STAGE_IMAGES + ("regions",)}, 0
+    for w in range(nwin):
+        ref = results[w]
+        for i in range(n):
+            f = w * n + i
+            ok = True
+            for key in STAGE_IMAGES:
+                if not np.array_equal(res[key][f], ref[key][i]):
+                    per_stage[key] += 1
+                    ok = False
+            got = [(int(g["label"]), int(g["r0"]), int(g["c0"]), int(g["r1"]), int(g["c1"]), int(g["area"]), int(g["sum_r"]), int(g["sum_c"]))
+                   for g in res["segs"][f, :res["nseg"][f]]]
+            exp = [(g["label"],) + tuple(g["bbox"]) + (g["area"], g["sum_r"], g["sum_c"]) for g in ref["segments"][i]]
+            segments += len(exp)
+            if got != exp:
+                per_stage["regions"] += 1
+                ok = False
+            bad += 0 if ok else 1
+    it_gpu, it_cpu = [int(v) for v in res["iters"]], [int(r["iters"]) for r in results]
+    return {"what": "the cpu_baseline sample's windows through swk_batch_run against the CPU restatement of the reference: IALM iteration "
+                    "count per window; gray, RPCA sparse, bilateral, threshold, opened and label images and the region records (label, bbox, "
+                    "area, centroid sums) of every frame, bit for bit",
+            "windows": nwin, "frames": nwin * n, "segments": segments, "mismatches": bad, "mismatching_frames": bad,
+            "mismatching_frames_per_stage": per_stage, "iters": it_gpu, "iters_oracle": it_cpu, "iters_equal": it_gpu == it_cpu}
+
+
+def count_loop_parity(clf, clf_state, flist, crop_region, roi_mask, n, windows):
+    """... and at the level the metric names, the swift count: the head of the count_loop clip through the counting loop (HIP path) and
+    through the CPU restatement's pipeline (its segments, the batch-1 CPU classifier on the same weights, the same tracker and event
+    rules; oracle/pipeline_ref.py, the checker of tests/test_baseline_configs.py).  Belongs to the cpu_baseline leg: CPU reference
+    work outside every timed region."""
+    from swiftwatcher_amd import pipeline
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd.io_frames import ArrayReader
+    from oracle import pipeline_ref
+    sub = flist[:n * windows]
+    events = pipeline.swift_counting_algorithm(ArrayReader(list(sub)), crop_region, roi_mask, queue_size=n, classifier=clf, keep_stages=True)
+    t0 = time.perf_counter()
+    info = pipeline_ref.oracle_frames(sub, crop_region, queue_size=n)
+    keep, unsure = None, 0
+    if clf_state is not None:
+        keep, _, unsure = pipeline_ref.classify_keep(clf_state, info)
+    events_orc = pipeline_ref.track(info, roi_mask, keep)
+    dt = time.perf_counter() - t0
+    same = pipeline_ref.event_signature(events) == pipeline_ref.event_signature(events_orc)
+    return {"what": "the first %d windows (%d frames) of the count_loop clip: swift_counting_algorithm on the HIP path against the CPU "
+                    "restatement's pipeline (segments, batch-1 CPU classifier on the same weights, tracker, event rules)" % (windows, len(sub)),
+            "frames": len(sub), "count": int(ec.count_swifts(events)), "count_oracle": int(ec.count_swifts(events_orc)),
+            "events": len(events), "events_oracle": len(events_orc), "events_identical": bool(same),
+            "segments_oracle": sum(len(i["segments"]) for i in info),
+            "kept_oracle": (sum(sum(k) for k in keep) if keep is not None else None),
+            "decisions_within_1e-3_of_a_tie": int(unsure), "oracle_s": round(dt, 1)}
+
+
+def reference_call_pattern(ctx_device, clf, args, geo, clf_state=None):
     """The reference's own call pattern from host 1080p frames (rank 0, N = 1): sub-results of the line, never `value`."""
     import numpy as np
     from swiftwatcher_amd import pipeline, synthetic
@@ -282,14 +398,132 @@ def reference_call_pattern(ctx_device, clf, args, geo):
         loop["roi_stream_presegmenting_reader_8"] = run_loop(lambda c: PresegmentingReader(stream(c), queue_size=n, windows=8, device=ctx_device), clf)
         if "error" not in loop["roi_stream"]:
             loop["roi_stream"]["input_mb_per_frame"] = round(os.path.getsize(paths[1]) / len(flist) / 1e6, 3)
+    if args.parity_windows > 0 and not args.no_cpu_baseline:
+        try:
+            loop["reference_pattern"]["parity"] = count_loop_parity(clf, clf_state, flist, crop_region, roi_mask, n,
+                                                                    min(args.parity_windows, args.loop_windows))
+        except Exception as exc:          # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            loop["reference_pattern"]["parity"] = {"error": repr(exc)}
     out["count_loop"] = dict(loop["reference_pattern"], roi_stream=loop["roi_stream"],
                              roi_stream_windows_per_call_8=loop["roi_stream_windows_per_call_8"],
                              presegmenting_reader_8=loop["presegmenting_reader_8"],
                              roi_stream_presegmenting_reader_8=loop["roi_stream_presegmenting_reader_8"],
                              what="swift_counting_algorithm as __main__.py:56-100 runs it: get_n_frames -> FrameQueue() -> classifier(frame.segments) "
                                   "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory played %d times, "
-                                  "--classify on (the bench's calibrated head)" % (len(flist), cycles),
+                                  "--classify on (%s)" % (len(flist), cycles, getattr(args, "weights_note", "the bench's classifier")),
                              windows_per_call_8=loop["windows_per_call_8"], no_classify=loop["reference_pattern_no_classify"])
+    return out
+
+
+def video_sharded_leg(args, rank, world, local, clf):
+    """BASELINE configs 4 / 5 as worded: every rank counts its own VIDEOS end to end -- reader -> FrameQueue -> classifier -> tracker ->
+    events -> count (pipeline.swift_counting_algorithm, the loop of __main__.py:56-100, over a reader that segments eight queue-fuls
+    ahead) -- videos round-robin over the ranks like the reference's `for src_filepath in src_filepaths` (__main__.py:21) would be
+    sharded, and ONE all_gather of (predicted, rejected, frames) per video at the end (RCCL when the ranks own GPUs; io_data.py:113 is
+    the count).  N <= 4: 1080p frames in host memory (config 4); N > 4: 4K videos as ROI stream files, 850 x 425 ROI (config 5).
+    Every rank calls this (collectives inside); returns the sub-result on rank 0, None elsewhere."""
+    import tempfile
+    import numpy as np
+    import torch
+    from swiftwatcher_amd import pipeline, synthetic
+    from swiftwatcher_amd import distributed as swd
+    from swiftwatcher_amd import event_classification as ec
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.io_frames import ArrayReader, PresegmentingReader
+    from swiftwatcher_amd.io_roi_stream import RoiFrame, RoiStreamReader, RoiStreamWriter, margin_rect
+    big = world > 4
+    n, nf = 21, 21 * args.video_windows
+    if big:
+        geo, frame_hw, corners = synthetic.P3, (2160, 3840), [(1580, 1240), (2260, 1244)]          # a 680-px chimney of a 4K frame
+    else:
+        geo, frame_hw, corners = synthetic.P2, (1080, 1920), [(790, 620), (1130, 622)]              # SURVEY 8d: 340 px at 1080p
+    crop_region = img.generate_crop_region(corners)
+    (x0, y0), (x1, y1) = crop_region
+    Hc, Wc = y1 - y0, x1 - x0
+    assert (Hc, Wc) == (geo["Hc"], geo["Wc"]), (Hc, Wc)
+    roi_mask = np.zeros((Hc, Wc), np.uint8)
+    roi_mask[int(0.47 * Hc):, int(0.1 * Wc):int(0.9 * Wc)] = 255
+    dev = torch.device("cuda", local)
+    videos = world * args.videos_per_gpu
+    tmp = tempfile.TemporaryDirectory()
+
+    def make_reader(i):
+        """video i: a seeded scene built on the GPU (same statistics as synthetic.roi_window), oldest frame first"""
+        roi = synthetic.roi_stream_torch(dev, nf, Hc, Wc, seed=77000 + i, birds=geo["birds"], bird_len=geo["bird_len"],
+                                         bird_wid=geo["bird_wid"]).cpu().numpy()
+        if not big:
+            frames = np.full((nf,) + frame_hw + (3,), 128, np.uint8)
+            frames[:, y0:y1, x0:x1] = roi
+            return ArrayReader([frames[k] for k in range(nf)])
+        ya, yb, xa, xb = margin_rect(frame_hw, crop_region)
+        path = os.path.join(tmp.name, "video%d.swkroi" % i)
+        with RoiStreamWriter(path, frame_hw, crop_region) as w:          # the stored rectangle only: no 25-MB 4K frames are made
+            rect = np.full((yb - ya, xb - xa, 3), 128, np.uint8)
+            for k in range(nf):
+                rect[y0 - ya:y1 - ya, x0 - xa:x1 - xa] = roi[k]
+                w.append(RoiFrame(rect, (ya, xa), frame_hw + (3,)))
+        return RoiStreamReader(path, device=local)
+
+    def count_video(reader):
+        pre = PresegmentingReader(reader, crop_region, queue_size=n, windows=8, device=local)
+        events = pipeline.swift_counting_algorithm(pre, crop_region, roi_mask, queue_size=n, classifier=clf, device=local)
+        count = int(ec.count_swifts(events))
+        return (count, len(events) - count, nf)
+
+    def rewind(reader):
+        if isinstance(reader, RoiStreamReader):
+            path = reader.filepath
+            reader.close()
+            return RoiStreamReader(path, device=local)
+        return ArrayReader(reader.frames)
+
+    mine = swd.shard(videos, rank, world)
+    failed, local_counts, dt = 0, {}, 0.0
+    try:
+        readers = {i: make_reader(i) for i in mine}
+        for i in mine:                                   # untimed first play: allocations, HIP graphs of the window sizes, page faults
+            count_video(readers[i])
+            readers[i] = rewind(readers[i])
+        torch.cuda.synchronize()
+        swd.barrier()
+        t0 = time.perf_counter()
+        for i in mine:
+            local_counts[i] = count_video(readers[i])
+        torch.cuda.synchronize()
+        swd.barrier()
+        dt = time.perf_counter() - t0
+    except Exception:          # noqa: BLE001  (every rank must still reach the collectives below)
+        import traceback
+        traceback.print_exc()
+        failed = 1
+        local_counts = {i: (-1, -1, 0) for i in mine}
+    failed = int(swd.max_over_ranks(failed))
+    dt_max = swd.max_over_ranks(dt)
+    table = swd.gather_counts(local_counts, videos)          # THE collective of the path: (predicted, rejected, frames) per video
+    out = None
+    if rank == 0:
+        out = {"what": "config %s: %d video(s) of %d frames, one per GPU, each counted end to end by its rank (reader that segments 8 "
+                       "queue-fuls ahead -> FrameQueue -> classifier -> tracker -> events -> count), per-video (predicted, rejected, "
+                       "frames) gathered with one all_gather over %s"
+                       % ("5 (4K videos as ROI stream files, 850x425 ROI)" if big else "4 (1080p frames in host memory, 424x212 ROI)",
+                          videos, nf, (torch.distributed.get_backend() if torch.distributed.is_initialized() else "no process group (one rank)")),
+               "videos": videos, "frames_per_video": nf, "classifier": getattr(args, "weights_note", None) if clf is not None else "off"}
+        if failed:
+            out["error"] = "a rank failed (see stderr)"
+        else:
+            total = int(table[:, 2].sum())
+            out.update(value=round(total / dt_max, 1), unit="frames/s", ms=round(dt_max * 1e3, 2),
+                       per_video_counts=[[int(v) for v in row] for row in table.tolist()])
+            # what a single process gets for the same videos (the first and the last; every one with --verify-all-videos)
+            check = list(range(videos)) if args.verify_all_videos else sorted({0, videos - 1})
+            same = True
+            for i in check:
+                same = same and tuple(int(v) for v in table[i].tolist()) == count_video(make_reader(i))
+            out["counts_equal_single_rank"] = bool(same)
+            out["verified_videos"] = check
+    tmp.cleanup()
     return out
 
 
@@ -360,15 +594,25 @@ def main():
     def segment_step():
         ctx.batch_run_raw(inp, params, out)      # synchronous on the library's own stream
 
-    clf = None
+    clf, sd, use_model_pt = None, None, False
     kept_total = [0, 0]
     if classify:
-        # Random-init weights of the architecture (no checkpoint travels to the GPU box).  Random weights put every
+        from swiftwatcher_amd.segment_classification import SegmentClassifier, SqueezeNet10
+        model_pt = os.path.join(ROOT, "tests", "golden", "classifier_model_pt.npz")
+        use_model_pt = args.weights == "model_pt" or (args.weights == "auto" and os.path.exists(model_pt))
+    if classify and use_model_pt:
+        # the reference's own weights (swiftwatcher/model.pt: its 52 tensors travel with the tests as arrays, no checkpoint file does)
+        g = np.load(model_pt)
+        sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
+        args.weights_note = "model.pt's weights (tests/golden/classifier_model_pt.npz)"
+        clf = SegmentClassifier.from_state_dict(sd, device=dev, batch_size=args.cls_batch, cropped=not args.full_network)
+    elif classify:
+        # Random-init weights of the architecture (--weights calibrated, or the tensor file is absent).  Random weights put every
         # crop in one class, so the head bias is calibrated on the stream's own segments: with both pre-activations
         # held positive (ReLU inactive) the score difference is affine in the bias, and the median segment is put on
         # the decision boundary -- about half of the segments are then kept, and both branches of the keep rule and
         # the per-frame reduction see real work.
-        from swiftwatcher_amd.segment_classification import SegmentClassifier, SqueezeNet10
+        args.weights_note = "random-init weights with the head bias calibrated on the stream"
         # He-normal weights (torch's default init leaves the head insensitive to the input below float32 resolution)
         gen = torch.Generator().manual_seed(20190816)
         sd = SqueezeNet10(2).state_dict()
@@ -438,7 +682,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    redo0 = ctx.redo_batches
+    redo0, redo_w0 = ctx.redo_batches, ctx.redo_windows
     dt_max, prof, bpe, net = timed(step)
     overlapped = None
     if args.overlap and clf is not None:
@@ -487,6 +731,9 @@ def main():
     seg_only = timed(segment_step) if clf is not None else None
     redo = ctx.redo_batches - redo0
 
+    # ---- configs 4 / 5 as worded: videos sharded over the ranks, per-video counts gathered (every rank takes part) ----
+    video_sharded = video_sharded_leg(args, rank, world, local, clf) if args.video_windows > 0 else None
+
     # ---- per-rank counts gathered over RCCL (the only collective of the path) ----
     it_host = iters.cpu().numpy()
     nseg_host = nseg.cpu().numpy()
@@ -510,13 +757,15 @@ def main():
                 # the sparse-image stores and most of the f16 copy of Y/mu)
                 total_bytes = int(bpe * elems)
             achieved = total_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
-            traffic = None
+            traffic, traffic_source = None, None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_ialm_pass.json")
             if os.path.exists(pmc_file):
                 try:       # PMC passes are separate rocprofv3 runs (tools/pmc_pass.sh); valid for the same n and ROI
                     pmc = json.load(open(pmc_file))
                     if pmc.get("n") == n and pmc.get("P") == P and pmc.get("variant", 2) == variant:
                         traffic = int(pmc["hbm_bytes_per_window_pass"] * nwin)
+                        traffic_source = ("profiles/pmc_ialm_pass.json: separate rocprofv3 --pmc runs of %s (the kernel body is unchanged "
+                                          "since), NOT counters of this run" % pmc.get("measured_at", "round 2, commit 4662110's parent"))
                 except Exception:
                     traffic = None
             # the same launches against the f64 matrix pipe: MFMAs per 16-pixel tile = NB x NK (A update) + 4 x NB (NB + 1) / 2
@@ -538,7 +787,9 @@ def main():
                     "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
                     "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
                     "bytes_per_element_iteration": round(total_bytes / max(elems * float(it_host.sum()) * args.steps, 1.0), 2),
-                    "pass_variant": variant,
+                    "byte_class": variant, "traffic_source": traffic_source,
+                    "roofline_definition": "r3: bound = f64 execution unit (executed MFMA flop incl. padded k-steps / launch time); hbm fraction nested",
+                    "useful_flops_frac": round(4.0 * n * n * P * float(it_host.sum()) * args.steps / max(flop, 1.0), 4),
                     "mfma_per_tile": mfma_per_tile,
                     # the same element-iterations priced at SURVEY 8(d)'s 33 B (the A/Y formulation this kernel
                     # replaces): informational, NOT what "achieved" uses
@@ -564,12 +815,12 @@ def main():
                        "roi": [Wc, Hc], "frame_batch": n, "windows_per_step": nwin,
                        "ialm_iters_mean": round(float(it_host.mean()), 2),
                        "segments_per_frame": round(float(nseg_host.mean()), 2),
-                       "classify": ("every segment through SqueezeNet-1.0 (fp32, eval mode, %s, random-init weights with the "
-                                    "head bias calibrated on the stream): %d segments/step, %d kept"
-                                    % ("full 224x224 network" if args.full_network else "receptive-field cropped",
+                       "classify": ("every segment through SqueezeNet-1.0 (fp32, eval mode, %s, %s): %d segments/step, %d kept"
+                                    % ("full 224x224 network" if args.full_network else "receptive-field cropped", args.weights_note,
                                        kept_total[1], kept_total[0])) if clf else "off (--no-classify)",
                        "parallelism": "windows sharded per GPU, no data-path collective"},
-            "redo_batches": int(redo), "guard_windows": int(ctx.guard_windows),
+            "redo_batches": int(redo), "redo_windows": int(ctx.redo_windows - redo_w0), "guard_windows": int(ctx.guard_windows),
+            "refined_windows": dict(zip(("refined", "given_up"), ctx.refined_windows)),
             "per_rank": [{"rank": r, "frames": int(table[r, 2]), "frames_per_s": round(float(table[r, 2]) / max(float(rank_ms[r]) * 1e-6, 1e-9), 1),
                           "kept_or_found": int(table[r, 0]), "ialm_iterations": int(table[r, 1])} for r in range(world)],
             "launched_by": "bench.py" if os.environ.get("SWK_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
@@ -601,6 +852,8 @@ def main():
             res["segment_only"] = {"metric": "frames/sec (segment) on 1080p ROI batches", "value": round(total_frames / so_dt, 2),
                                    "ms_per_step": round(so_dt / args.steps * 1e3, 3), "roofline": pass_roofline(so_prof, so_bpe),
                                    "kernel_ms_per_step": kernel_ms(so_prof)}
+        if video_sharded is not None:
+            res["video_sharded"] = video_sharded
         if world == 1 and not args.no_drop_in:
             # the same segment step fed from host memory (ROI frames in page-locked memory, one copy per batch), 32 windows
             hw_ = min(nwin, 32)
@@ -619,7 +872,7 @@ def main():
             del host
             if args.size == "P2":
                 try:
-                    res.update(reference_call_pattern(local, clf, args, geo))
+                    res.update(reference_call_pattern(local, clf, args, geo, clf_state=sd if clf is not None else None))
                 except Exception as exc:          # noqa: BLE001  (sub-results only: the line above them stands)
                     import traceback
                     traceback.print_exc()
@@ -627,7 +880,9 @@ def main():
                     res["count_loop"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:          # the CPU baseline is a single-GPU-run companion (rank 0 at N = 1 only)
             try:
-                res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None)
+                sample = {}
+                res["cpu_baseline"] = cpu_baseline(n, Hc, Wc, args.cpu_windows, clf is not None, sample=sample)
+                res["parity"] = sample_parity(ctx, sample["rois"], sample["results"], n)
             except Exception as exc:          # noqa: BLE001
                 import traceback
                 traceback.print_exc()

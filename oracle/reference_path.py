@@ -258,14 +258,15 @@ def ialm_defined(X, lmbda=0.01, tol=0.001, maxiter=100, return_iters=False):
     return (A, E, k) if return_iters else (A, E)
 
 
-def rpca(gray_frames, **kw):
-    """image_filtering.py:220-253: list of n (H,W) u8 frames -> list of n (H,W) u8."""
+def rpca(gray_frames, return_iters=False, **kw):
+    """image_filtering.py:220-253: list of n (H,W) u8 frames -> list of n (H,W) u8 (and the IALM's iteration count on request)."""
     stack = np.array(gray_frames)
     n, H, W = stack.shape
     cols = np.transpose(stack.reshape(n, H * W))              # (P, n), column j = frame j
-    _, E = ialm_defined(cols, **kw)
+    _, E, k = ialm_defined(cols, return_iters=True, **kw)
     S = rpca_epilogue(E)
-    return [np.reshape(S[:, i], (H, W)) for i in range(n)]
+    out = [np.reshape(S[:, i], (H, W)) for i in range(n)]
+    return (out, k) if return_iters else out
 
 
 # --------------------------------------------------------------------------
@@ -283,7 +284,7 @@ def window(roi_bgr, **overrides):
     p.update(overrides)
     n = roi_bgr.shape[0]
     gray = [bgr2gray(roi_bgr[i], p["gray_mode"]) for i in range(n)]
-    sparse = rpca(gray, lmbda=p["lmbda"], tol=p["tol"], maxiter=p["maxiter"])
+    sparse, iters = rpca(gray, return_iters=True, lmbda=p["lmbda"], tol=p["tol"], maxiter=p["maxiter"])
     bil = [bilateral_u8(f, p["bil_d"], p["bil_sigma_color"], p["bil_sigma_space"], p["bil_fma"])
            for f in sparse]
     thr = [thresh_tozero_u8(f, p["thresh"]) for f in bil]
@@ -292,4 +293,4 @@ def window(roi_bgr, **overrides):
     segs = [regionprops_u8(l) for l in lab]
     return dict(gray=np.stack(gray), rpca=np.stack(sparse), bilateral=np.stack(bil),
                 thresh=np.stack(thr), opened=np.stack(opened), labels=np.stack(lab),
-                segments=segs)
+                segments=segs, iters=iters)

@@ -1,4 +1,4 @@
-"""ctypes binding of libswk.so (include/swk.h).  No torch, no numpy arithmetic: this module
+"""ctypes binding of libswk.so (include/swk.h; the A/B switches and counters of include/swk_debug.h).  No torch, no numpy arithmetic: this module
 only marshals pointers.  There is no CPU fallback -- if the HIP library is missing or no
 gfx950 device is usable, importing is fine but creating a Context raises SwkError."""
 import ctypes
@@ -95,8 +95,11 @@ _SIGS = {
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_set_norm_guard": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_guard_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_set_start_refine": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
+    "swk_prof_refined_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_redo_batches": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_prof_redo_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "swk_nhwc_bias_relu_place": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 8 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6),
     "swk_set_cnn_tuning": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     "swk_nhwc_conv7x7s2_bias_relu": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
@@ -338,6 +341,17 @@ class Context:
         self._check(self._lib.swk_prof_guard_windows(self._h, ctypes.byref(v)))
         return v.value
 
+    def set_start_refine(self, tau):
+        """Estimated first-iteration error above which a window gets the accurate start (csrc/ialm_refine.hip); <= 0: never."""
+        self._check(self._lib.swk_set_start_refine(self._h, float(tau)))
+
+    @property
+    def refined_windows(self):
+        """(windows whose first iteration was refined, windows that wanted it and did not get it) since the context was made."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.swk_prof_refined_windows(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def set_norm_speculation(self, factor):
         self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))
 
@@ -363,6 +377,12 @@ class Context:
     def redo_batches(self):
         v = ctypes.c_int64(0)
         self._check(self._lib.swk_prof_redo_batches(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def redo_windows(self):
+        v = ctypes.c_int64(0)
+        self._check(self._lib.swk_prof_redo_windows(self._h, ctypes.byref(v)))
         return v.value
 
     def set_eig_method(self, method):

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void k_ialm_pass_v1(IalmBuffers b)
     const int w = blockIdx.y;
     const IalmWin &st = b.win[w];
     if (st.done) return;
+    if (MODE == 0 && st.int_gram) return;        // the start pass's only product already came from k_gram_u8 (exact X^T X)
     const int t = threadIdx.x;
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;
     const double inv_mu2 = st.nxt.inv_mu, thr2 = st.nxt.thr;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_v2(IalmBuffers b)
     const int w = blockIdx.y;
     const IalmWin &st = b.win[w];
     if (st.done) return;
+    if (MODE == 0 && st.int_gram) return;        // the start pass's only product already came from k_gram_u8 (exact X^T X)
     const int n = b.n, P = b.P;
     const unsigned ps32 = (unsigned)b.pstride, P32 = (unsigned)P;
     const double inv_mu = st.cur.inv_mu, thr = st.cur.thr, mu = st.cur.mu;

@@ -21,7 +21,7 @@ enum Slot {
     SL_ROI = 0, SL_X, SL_S, SL_BIL, SL_THR, SL_OPEN, SL_LAB8, SL_LAB32, SL_A, SL_Y, SL_E, SL_PN,
     SL_BM, SL_VPREV, SL_GPART, SL_ZZPART, SL_WIN, SL_ACTIVE, SL_PARENT, SL_ROOTBITS, SL_WORDPREFIX,
     SL_NCOMP, SL_TABLE, SL_SUMS, SL_SEGS, SL_NSEG, SL_ITERS, SL_TMP_IN, SL_TMP_OUT, SL_COLORW, SL_SPACEW,
-    SL_TAPDR, SL_TAPDC, SL_SALT, SL_WIDE, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
+    SL_TAPDR, SL_TAPDC, SL_SALT, SL_WIDE, SL_REDO_X, SL_REDO_S, SL_REDO_X2, SL_REDO_S2, SL_SEGOFFS, SL_CL_CROPS, SL_CL_OFFS, SL_CL_HW, SL_CL_PATCH, SL_CL_NET, SL_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int fam; };
@@ -50,7 +50,10 @@ struct swk_ctx {
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     double norm_guard = 1e-3;      // M-state pass: |ratio / tol - 1| below this does not decide (the window is rerun with the f64 norm)
     int64_t guard_windows = 0;     // windows rerun for that reason
-    int64_t redo_batches = 0;
+    double start_refine = 3e-5;    // estimated first-iteration error above which a window gets the accurate start (ialm_refine.hip)
+    int64_t refined_windows = 0, unrefined_windows = 0;
+    int64_t redo_batches = 0;      // batches in which a guess of the M-state pass failed ...
+    int64_t redo_windows = 0;      // ... and the windows that were run again for it
     int last_eig_sweeps = 0;       // largest IalmWin::sweeps of the last batch (Newton-Schulz iterations, or 100 + Jacobi sweeps)
     int last_int_start = 0;        // windows of the last batch whose first Gram matrix came from the integer matrix cores
     int use_gram8 = 1;             // M-state pass: first Gram matrix from k_gram_u8 (A/B knob)
@@ -286,7 +289,8 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     const int check_from = 6;     // no window converges earlier (mu grows 1.5x per iteration)
     // window statistics (||X||_F, max) and, for the M-state pass, the first Gram matrix in the same read of X
     // on the integer matrix cores; windows it does not cover get the f64 start pass below
-    b.use_gram8 = (mstate && ctx->use_gram8 && gram_u8_supported(b)) ? 1 : 0;
+    b.use_gram8 = ((mstate || variant == 2 || variant == 1) && ctx->use_gram8 && gram_u8_supported(b)) ? 1 : 0;
+    b.refine = wide ? 0.0 : ctx->start_refine;
     { Timed t(ctx, SWK_K_IALM_STATS);
       if (b.use_gram8) launch_gram_u8(s, b); else launch_ialm_stats(s, b);
       launch_ialm_init(s, b, lmbda); }
@@ -300,6 +304,10 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         else launch_ialm_small(s, b, k, lmbda, tol, maxiter, ctx->eig_method);
     };
     small_step(0);
+    // windows that step found ill-conditioned get their first iteration's matrix B_1 again, from a double-double Cholesky factor
+    // of the exact integer X^T X -- of a double-double M_1^T M_1 where the window had no integer start -- (one workgroup per flagged
+    // window; the others leave at the first branch)
+    if (b.refine > 0.0) { Timed t(ctx, SWK_K_IALM_SMALL); launch_ialm_refine_start(s, b); }
     for (int k = 1; k <= maxiter + 2; ++k) {
         // convergence is polled two iterations late so the host never stalls the queue; the launches made
         // meanwhile for an already finished batch return at their first branch
@@ -317,44 +325,72 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
         }
     }
     if (mstate) { Timed t(ctx, SWK_K_IALM_STATS); launch_select_sparse(s, b); }
+    ctx->last_win = b.win;
+    ctx->last_nwin = nwin;
     if (mstate && (b.spec > 0.0 || b.nspec > 0.0 || b.guard > 0.0)) {
-        // did any window stop right after a pass that had its sparse-image stores switched off?
+        // Windows the M-state pass could not finish on its own terms (IalmWin::redo): bits 0 / 1 = a guess failed (the window stopped
+        // right after a pass that had its sparse-image stores switched off, or a partial norm could not rule out that an iteration
+        // was the last); bit 2 = the float32 stopping norm fell inside the guard band around the tolerance.  Only THOSE windows run
+        // again -- the first kind together, in one call with the guesses off; the second kind through the A/Y-state pass (norm in
+        // float64, statement by statement the reference's :293-297) -- and their sparse images, iteration counts and diagnostics
+        // replace the windows' entries.  (Until round 3 one failed guess reran the whole batch.)
         std::vector<IalmWin> hw(nwin);
         HIPCHK(ctx, hipMemcpyAsync(hw.data(), b.win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
+        std::vector<int> guess, band;
         int redo = 0;
-        for (int w = 0; w < nwin; ++w) redo |= hw[w].redo;
+        for (int w = 0; w < nwin; ++w) {
+            redo |= hw[w].redo;
+            if (hw[w].redo & 3) guess.push_back(w);
+            else if (hw[w].redo & 4) band.push_back(w);
+        }
         if (redo & 3) {
             // windows of one video behave alike: a guess that failed stays off for the next batches
             ctx->redo_batches += 1;
+            ctx->redo_windows += (int64_t)guess.size();
             if (redo & 1) ctx->sparse_backoff = 64;
             if (redo & 2) ctx->norm_backoff = 64;
-            return run_ialm(ctx, dX, nwin, n, P, lmbda, tol, maxiter, want_A, want_E, dS, h_iters, d_iters, false);
         }
-        if (redo & 4) {
-            // windows whose float32 stopping norm fell inside the guard band: each of them alone through the A/Y-state pass (norm in
-            // float64, statement by statement the reference's :293-297); its sparse image lands in the window's planes of dS, its
-            // state struct replaces the window's entry (iteration count, diagnostics)
-            for (int w = 0; w < nwin; ++w) {
-                if (!(hw[w].redo & 4)) continue;
-                ctx->guard_windows += 1;
-                int rc1 = run_ialm(ctx, dX + (size_t)w * n * P, 1, n, P, lmbda, tol, maxiter, false, false, dS + (size_t)w * n * P, nullptr,
-                                   nullptr, false, 2);
-                if (rc1) return rc1;
-                IalmWin one;
-                HIPCHK(ctx, hipMemcpyAsync(&one, ctx->last_win, sizeof(IalmWin), hipMemcpyDeviceToHost, s));
-                HIPCHK(ctx, hipStreamSynchronize(s));
-                one.pass_b16 = hw[w].pass_b16;          // the roofline books the M-state passes the window did run
-                one.int_gram = hw[w].int_gram;
-                hw[w] = one;
+        ctx->guard_windows += (int64_t)band.size();
+        const int64_t pstride = ctx->pstride;
+        const int fpad = ctx->fpad;
+        for (int kind = 0; kind < 2; ++kind) {
+            const std::vector<int> &list = kind == 0 ? guess : band;
+            if (list.empty()) continue;
+            const int cnt = (int)list.size();
+            const size_t wbytes = (size_t)n * P;
+            // the listed windows side by side: their pixels gathered, their sparse images scattered back
+            // (a slot pair per kind: the run of the first kind may itself send windows of ITS batch through the second)
+            uint8_t *gx, *gs;
+            NEED(ctx, kind == 0 ? SL_REDO_X : SL_REDO_X2, (size_t)cnt * wbytes + 4, gx);
+            NEED(ctx, kind == 0 ? SL_REDO_S : SL_REDO_S2, (size_t)cnt * wbytes, gs);
+            for (int i = 0; i < cnt; ++i)
+                HIPCHK(ctx, hipMemcpyAsync(gx + (size_t)i * wbytes, dX + (size_t)list[i] * wbytes, wbytes, hipMemcpyDeviceToDevice, s));
+            const int rc1 = run_ialm(ctx, gx, cnt, n, P, lmbda, tol, maxiter, false, false, gs, nullptr, nullptr, false, kind == 0 ? variant : 2);
+            if (rc1) return rc1;
+            std::vector<IalmWin> sub(cnt);
+            HIPCHK(ctx, hipMemcpyAsync(sub.data(), ctx->last_win, (size_t)cnt * sizeof(IalmWin), hipMemcpyDeviceToHost, s));
+            for (int i = 0; i < cnt; ++i)
+                HIPCHK(ctx, hipMemcpyAsync(dS + (size_t)list[i] * wbytes, gs + (size_t)i * wbytes, wbytes, hipMemcpyDeviceToDevice, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+            for (int i = 0; i < cnt; ++i) {
+                IalmWin one = sub[i];
+                one.pass_b16 += hw[list[i]].pass_b16;          // the roofline books every pass a window ran, the abandoned ones included
+                hw[list[i]] = one;
             }
-            // (the slots may have moved: NEED only grows them, and SL_WIN was sized for nwin before)
+        }
+        if (!guess.empty() || !band.empty()) {
+            // the nested runs used the window-state slot and the A / Y workspaces for their own (smaller) batches: this batch's
+            // entries go back, and the context describes THIS batch again
+            NEED(ctx, SL_WIN, (size_t)nwin * sizeof(IalmWin), b.win);
             HIPCHK(ctx, hipMemcpyAsync(b.win, hw.data(), (size_t)nwin * sizeof(IalmWin), hipMemcpyHostToDevice, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
+            ctx->pstride = pstride;
+            ctx->fpad = fpad;
+            ctx->last_win = b.win;
+            ctx->last_nwin = nwin;
         }
     }
-    ctx->last_win = b.win;
-    ctx->last_nwin = nwin;
     (void)h_iters; (void)d_iters;
     return SWK_OK;
 }
@@ -374,6 +410,8 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     for (int w = 0; w < nwin; ++w) {
         it[w] = hw[w].iter; ctx->window_iters += hw[w].iter; ctx->pass_b16 += hw[w].pass_b16;
         ctx->last_int_start += hw[w].int_gram ? 1 : 0;
+        if (hw[w].refine == 2) ctx->refined_windows += 1;
+        else if (hw[w].refine != 0) ctx->unrefined_windows += 1;
         if (hw[w].sweeps > ctx->last_eig_sweeps) ctx->last_eig_sweeps = hw[w].sweeps;
     }
     if (h_iters) memcpy(h_iters, it.data(), (size_t)nwin * 4);
@@ -645,6 +683,27 @@ int32_t swk_prof_redo_batches(swk_ctx *ctx, int64_t *batches)
 {
     if (!ctx || !batches) return SWK_ERR_ARG;
     *batches = ctx->redo_batches;
+    return SWK_OK;
+}
+
+int32_t swk_set_start_refine(swk_ctx *ctx, double tau)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    ctx->start_refine = tau;
+    return SWK_OK;
+}
+int32_t swk_prof_refined_windows(swk_ctx *ctx, int64_t *refined, int64_t *unrefined)
+{
+    if (!ctx) return SWK_ERR_ARG;
+    if (refined) *refined = ctx->refined_windows;
+    if (unrefined) *unrefined = ctx->unrefined_windows;
+    return SWK_OK;
+}
+
+int32_t swk_prof_redo_windows(swk_ctx *ctx, int64_t *windows)
+{
+    if (!ctx || !windows) return SWK_ERR_ARG;
+    *windows = ctx->redo_windows;
     return SWK_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <atomic>
 #include "swk.h"
+#include "swk_debug.h"
 
 namespace swk {
 
@@ -74,6 +75,11 @@ struct IalmWin {
     int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
     unsigned long long pass_b16;   // algorithmic bytes per element moved by the passes 1..iter of this window, in 1/16 B
     double zf2;                    // ||(G/s)^(-1/2)||_F^2 of the last Newton-Schulz solve (0: none yet): where the next solve's bound starts
+    double cond_sum;               // ||G_1||_F sum_i 1 / lambda_i(G_1) of the first solve (>= cond(G_1)): the ill-conditioning estimate
+    int refine;                    // accurate first iteration (ialm_refine.hip): 0 not needed, 1 asked for by k_ialm_small (k = 0),
+                                   // 2 done, 3 given up (rank deficient: the standard route's defined result stands),
+                                   // 4 wanted but not done (a window without an integer start that is too large for one workgroup's
+                                   // double-double Gram matrix)
 };
 
 struct IalmBuffers {
@@ -95,6 +101,8 @@ struct IalmBuffers {
     double nspec;                  // M-state pass: ||Z|| formed every other iteration while above nspec * tol * ||X|| (<= 0: always)
     double guard;                  // M-state pass: relative half-width of the band around tol in which the float32 norm does
                                    // not decide (<= 0: off; the A/Y-state pass forms the norm in float64 and needs none)
+    double refine;                 // a window whose estimated first-iteration error eps * cond_sum / mu_0 exceeds this gets the accurate
+                                   // first iteration of ialm_refine.hip (<= 0: never)
     int nred;                      // Gram slabs the small-matrix kernel still has to sum (1 after k_gram_reduce)
     int fpad;                      // planes allocated per window in A, Y, E: n rounded up to 16
     int64_t pstride;               // plane pitch (elements) of A, Y, E: P rounded up to 16 -> 128-B aligned rows
@@ -114,6 +122,8 @@ void launch_ialm_small(hipStream_t s, const IalmBuffers &b, int k, double lmbda,
 // windows of 65 .. 128 frames: cyclic Jacobi with its matrices in global memory (work: 3 (n + 2)^2 doubles per window)
 void launch_ialm_small_wide(hipStream_t s, const IalmBuffers &b, int k, double lmbda, double tol, int maxiter, double *work);
 size_t ialm_small_wide_doubles(int n);
+// ialm_refine.hip: accurate first iteration (B_1) of the windows k_ialm_small flagged at k = 0; one launch after that step
+void launch_ialm_refine_start(hipStream_t s, const IalmBuffers &b);
 // sums the nblk Gram partial slabs of every live window into slab 0, in fixed order, chip-wide
 void launch_gram_reduce(hipStream_t s, const IalmBuffers &b);
 // ialm_gram8.hip: exact X^T X, sum of squares and max of every window on the i8 matrix cores

@@ -56,7 +56,8 @@ def test_regionprops(golden_dir):
 
 # ialm_47x94x21 = BASELINE config 1's ROI (480p clip, chimney 76 px wide) at the CLI's queue size: 92.8 k elements, where
 # 0.008 ||X||_F < 1.8 max(X) and the first shrinkage already clips the brightest sky pixels (23 iterations).
-IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64", "ialm_107x214x21", "ialm_47x94x21"]
+IALM_CASES = ["ialm_128x160x7", "ialm_64x96x21", "ialm_40x48x64", "ialm_64x96x64", "ialm_107x214x21", "ialm_47x94x21",
+              "ialm_47x94x64", "ialm_47x94x64_quiet", "ialm_30x40x64"]          # round 4: ill-conditioned windows (oracle/make_goldens_r4.py)
 # the BASELINE workload sizes: inputs regenerated from the seed (oracle/scenes.py), outputs of the reference stored as
 # iteration count, sha256 of the sparse image and A / E on sampled pixel rows (oracle/make_goldens_r2.py)
 SEEDED_CASES = ["ialm_212x424x21_seeded", "ialm_212x424x64_seeded", "ialm_425x850x21_seeded"]
