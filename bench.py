@@ -354,7 +354,10 @@ def reference_call_pattern(ctx_device, clf, args, geo, clf_state=None):
     import tempfile
     from swiftwatcher_amd.io_roi_stream import RoiStreamReader, write_roi_stream
     cycles = 3
-    clip = synthetic.full_frames(5, n * args.loop_windows, crop_region, birds=12)[::-1]          # oldest first
+    # with the reference's trained weights the clip's birds are the kind model.pt takes for swifts (synthetic.SWIFT_LIKE: 21 % kept; of
+    # the large dark ellipses of the headline stream it keeps none, and a loop without events would flatter the tracker's share)
+    birds = synthetic.SWIFT_LIKE if getattr(args, "swift_like", False) else dict(birds=12)
+    clip = synthetic.full_frames(5, n * args.loop_windows, crop_region, **birds)[::-1]          # oldest first
     flist = [clip[i] for i in range(n * args.loop_windows)]
     total = len(flist) * cycles
     roi_mask = np.zeros((212, 424), np.uint8)
@@ -412,7 +415,8 @@ def reference_call_pattern(ctx_device, clf, args, geo, clf_state=None):
                              roi_stream_presegmenting_reader_8=loop["roi_stream_presegmenting_reader_8"],
                              what="swift_counting_algorithm as __main__.py:56-100 runs it: get_n_frames -> FrameQueue() -> classifier(frame.segments) "
                                   "per popped frame -> the six tracker calls -> events; %d frames of 1080p in host memory played %d times, "
-                                  "--classify on (%s)" % (len(flist), cycles, getattr(args, "weights_note", "the bench's classifier")),
+                                  "--classify on (%s; %s)" % (len(flist), cycles, getattr(args, "weights_note", "the bench's classifier"),
+                                                               "14 small faint birds per frame" if getattr(args, "swift_like", False) else "12 large birds per frame"),
                              windows_per_call_8=loop["windows_per_call_8"], no_classify=loop["reference_pattern_no_classify"])
     return out
 
@@ -451,8 +455,8 @@ def video_sharded_leg(args, rank, world, local, clf):
 
     def make_reader(i):
         """video i: a seeded scene built on the GPU (same statistics as synthetic.roi_window), oldest frame first"""
-        roi = synthetic.roi_stream_torch(dev, nf, Hc, Wc, seed=77000 + i, birds=geo["birds"], bird_len=geo["bird_len"],
-                                         bird_wid=geo["bird_wid"]).cpu().numpy()
+        birds = synthetic.SWIFT_LIKE if getattr(args, "swift_like", False) else dict(birds=geo["birds"], bird_len=geo["bird_len"], bird_wid=geo["bird_wid"])
+        roi = synthetic.roi_stream_torch(dev, nf, Hc, Wc, seed=77000 + i, **birds).cpu().numpy()
         if not big:
             frames = np.full((nf,) + frame_hw + (3,), 128, np.uint8)
             frames[:, y0:y1, x0:x1] = roi
@@ -605,6 +609,7 @@ def main():
         g = np.load(model_pt)
         sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
         args.weights_note = "model.pt's weights (tests/golden/classifier_model_pt.npz)"
+        args.swift_like = True
         clf = SegmentClassifier.from_state_dict(sd, device=dev, batch_size=args.cls_batch, cropped=not args.full_network)
     elif classify:
         # Random-init weights of the architecture (--weights calibrated, or the tensor file is absent).  Random weights put every

@@ -76,7 +76,7 @@ int32_t swk_set_eig_method(swk_ctx *ctx, int32_t method);
 
 /* Accurate first iteration of ill-conditioned windows (csrc/ialm_refine.hip).  The Gram-matrix route squares cond(M); in iteration 1
  * (M_1 = c X, 1/mu largest) that costs about eps * cond(G_1) / mu_0 in A, and windows of few pixels and many frames carry that error
- * to the end.  A window whose estimate eps * ||G_1||_F sum_i 1/lambda_i / mu_0 exceeds `tau` (default 3e-5; <= 0 = never) gets B_1
+ * to the end.  A window whose estimate eps * ||G_1||_F sum_i 1/lambda_i / mu_0 exceeds `tau` (default 1e-5; <= 0 = never) gets B_1
  * from a double-double Cholesky factor of the exact integer X^T X (of a double-double M_1^T M_1 where the first shrinkage clips)
  * instead.  swk_prof_refined_windows: windows refined / wanted but given up (rank deficient, or too large for one workgroup's
  * double-double Gram matrix) since the context was made. */

@@ -50,7 +50,7 @@ struct swk_ctx {
     double sparse_spec = 16.0;     // M-state pass: sparse image stores start at 16 x tol (<= 0: every pass)
     double norm_guard = 1e-3;      // M-state pass: |ratio / tol - 1| below this does not decide (the window is rerun with the f64 norm)
     int64_t guard_windows = 0;     // windows rerun for that reason
-    double start_refine = 3e-5;    // estimated first-iteration error above which a window gets the accurate start (ialm_refine.hip)
+    double start_refine = 1e-5;    // estimated first-iteration error above which a window gets the accurate start (ialm_refine.hip)
     int64_t refined_windows = 0, unrefined_windows = 0;
     int64_t redo_batches = 0;      // batches in which a guess of the M-state pass failed ...
     int64_t redo_windows = 0;      // ... and the windows that were run again for it

@@ -181,3 +181,29 @@ def test_videos_sharded_over_two_ranks_on_the_gpu():
         expect.append([count, len(events) - count, len(clip)])
     assert table == expect
     assert sum(r[0] + r[1] for r in table) >= 1
+
+
+@pytest.mark.gpu
+def test_bench_video_sharded_leg_with_two_ranks_on_one_gpu():
+    """The line the driver runs on a multi-GPU node carries BASELINE configs 4 / 5 as worded: `bench.py --gpus 2` (self-launched ranks;
+    gloo, because the test box's two ranks share one GPU) -- every rank counts its own video end to end (reader that segments ahead ->
+    FrameQueue -> classifier -> tracker -> events -> count), ONE all_gather delivers the per-video (predicted, rejected, frames) table,
+    and rank 0's single-process recount of every video gives the same numbers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--windows", "4",
+                          "--no-cpu-baseline", "--no-drop-in", "--video-windows", "4", "--verify-all-videos"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    vs = line["video_sharded"]
+    assert line["n_gpus"] == 2 and vs["videos"] == 2 and vs["frames_per_video"] == 84, vs
+    assert vs["counts_equal_single_rank"] is True and vs["verified_videos"] == [0, 1]
+    assert [row[2] for row in vs["per_video_counts"]] == [84, 84] and vs["value"] > 0
+    # the trained weights keep a share of the clip's small faint birds: the gathered table is not all zeros
+    assert sum(row[0] + row[1] for row in vs["per_video_counts"]) >= 1, vs

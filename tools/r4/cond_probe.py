@@ -16,7 +16,7 @@ for name in ("ialm_40x48x64", "ialm_47x94x64", "ialm_47x94x64_quiet", "ialm_30x4
     frames = g["frames"]
     n, H, W = frames.shape
     rows = g["rows"]
-    for variant, tau in ((0, 0.0), (0, 3e-5), (1, 3e-5)):
+    for variant, tau in ((0, 0.0), (0, 1e-5), (1, 1e-5)):
         for method in (0, 1):
             ctx.set_ialm_variant(variant)
             ctx.set_eig_method(method)
@@ -30,7 +30,7 @@ for name in ("ialm_40x48x64", "ialm_47x94x64", "ialm_47x94x64_quiet", "ialm_30x4
                 int((sp != g["sparse"]).sum()), after[0] - before[0], after[1] - before[1]), flush=True)
     ctx.set_ialm_variant(0)
     ctx.set_eig_method(0)
-    ctx.set_start_refine(3e-5)
+    ctx.set_start_refine(1e-5)
     before = ctx.refined_windows
     res = ctx.batch_run(np.ascontiguousarray(frames), 1, n, stages=("gray", "rpca"))
     assert np.array_equal(res["gray"], frames)
