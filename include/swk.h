@@ -196,6 +196,15 @@ int32_t swk_thresh_tozero_u8(swk_ctx *ctx, const uint8_t *src, int64_t count, in
 /* grayscale_opening with SE (3,3) (image_filtering.py:319-322): [count][H][W] u8 */
 int32_t swk_grey_open3x3_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W,
                             uint8_t *dst);
+/* grayscale_opening with any SE (kh, kw) (image_filtering.py:319-322: scipy.ndimage.grey_opening(size=SE), border mode 'reflect',
+ * scipy's placement of even windows).  The reference's loop only asks for (3, 3) (data_structures.py:202: swk_batch_run's fused
+ * filter kernel and swk_grey_open3x3_u8); this is the stage function's general case. */
+int32_t swk_grey_open_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst);
+/* resize_frame (image_filtering.py:206-212): cv2.resize(frame, (dW, dH)) = INTER_LINEAR on 8-bit pixels, [count][H][W][channels] ->
+ * [count][dH][dW][channels].  PARITY UNPINNED (OpenCV 4.1.0's generic 8u arithmetic restated); dead code in the reference (both call
+ * sites are commented out, data_structures.py:179-181), kept for the completeness of the module's surface. */
+int32_t swk_resize_linear_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t channels, int32_t dH, int32_t dW,
+                             uint8_t *dst);
 /* cc_labeling (image_filtering.py:325-329) before the uint8 cast: int32 labels, and the
  * component count per plane. */
 int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W,

@@ -116,7 +116,19 @@ def grey_open_u8(src, size=(3, 3)):
     out = np.empty_like(src)
     rc = lib().orc_grey_open_u8(_p(src), H, W, int(size[0]), int(size[1]), _p(out))
     if rc:
-        raise ValueError("oracle grey opening supports odd window sizes only")
+        raise ValueError("bad opening window")
+    return out
+
+
+def resize_linear_u8(src, dsize):
+    """image_filtering.py:206-212: cv2.resize(frame, dsize=(width, height)), INTER_LINEAR (PARITY UNPINNED; dead code in the reference)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    H, W = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    dW, dH = int(dsize[0]), int(dsize[1])
+    out = np.empty((dH, dW) + ((ch,) if src.ndim == 3 else ()), np.uint8)
+    if lib().orc_resize_linear_u8(_p(src), H, W, ch, dH, dW, _p(out)):
+        raise MemoryError
     return out
 
 

@@ -138,9 +138,10 @@ ORC_API void orc_thresh_tozero_u8(const uint8_t *src, int64_t count, int thresh,
 /* ------------------------------------------------------------------------- */
 /* grayscale_opening: image_filtering.py:319-322 -> scipy.ndimage.grey_opening */
 /* (size=(kh,kw)): flat erosion then flat dilation, border mode 'reflect'      */
-/* (d c b a | a b c d | d c b a).  scipy centres an even window with origin    */
-/* shifted; only odd sizes are used by the reference ((3,3),                   */
-/* data_structures.py:202) and accepted here.  PINNED by golden fixtures.      */
+/* (d c b a | a b c d | d c b a).  The reference uses (3,3) only              */
+/* (data_structures.py:202); any size is accepted here (scipy's placement of   */
+/* an even window restated in flat_minmax).  PINNED by golden fixtures made    */
+/* with scipy through the reference's own function, odd and even sizes.        */
 /* ------------------------------------------------------------------------- */
 static inline int reflect_sym(int p, int len)
 {
@@ -153,12 +154,15 @@ static inline int reflect_sym(int p, int len)
 
 static void flat_minmax(const uint8_t *src, int H, int W, int kh, int kw, int is_max, uint8_t *dst)
 {
-    int rh = kh / 2, rw = kw / 2;
+    /* scipy.ndimage.grey_erosion(size=k) looks at offsets -k/2 .. k-1-k/2; grey_dilation at the mirrored ones (its origin is
+       negated, and shifted by one for an even size): the same for an odd size, one apart for an even one */
+    int lo_r = is_max ? -(kh - 1 - kh / 2) : -(kh / 2), hi_r = is_max ? kh / 2 : kh - 1 - kh / 2;
+    int lo_c = is_max ? -(kw - 1 - kw / 2) : -(kw / 2), hi_c = is_max ? kw / 2 : kw - 1 - kw / 2;
     for (int r = 0; r < H; ++r)
         for (int c = 0; c < W; ++c) {
             int acc = is_max ? 0 : 255;
-            for (int i = -rh; i <= rh; ++i)
-                for (int j = -rw; j <= rw; ++j) {
+            for (int i = lo_r; i <= hi_r; ++i)
+                for (int j = lo_c; j <= hi_c; ++j) {
                     int v = src[(int64_t)reflect_sym(r + i, H) * W + reflect_sym(c + j, W)];
                     if (is_max) { if (v > acc) acc = v; }
                     else        { if (v < acc) acc = v; }
@@ -169,12 +173,60 @@ static void flat_minmax(const uint8_t *src, int H, int W, int kh, int kw, int is
 
 ORC_API int orc_grey_open_u8(const uint8_t *src, int H, int W, int kh, int kw, uint8_t *dst)
 {
-    if (!(kh & 1) || !(kw & 1)) return -1;
+    if (kh < 1 || kw < 1) return -1;
     uint8_t *tmp = (uint8_t *)malloc((size_t)H * W);
     if (!tmp) return -2;
     flat_minmax(src, H, W, kh, kw, 0, tmp);
     flat_minmax(tmp, H, W, kh, kw, 1, dst);
     free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* resize_frame: image_filtering.py:206-212 -> cv2.resize(frame, (w, h)),      */
+/* INTER_LINEAR on 8-bit pixels.  PARITY UNPINNED (and dead code in the        */
+/* reference: its two call sites are commented out, data_structures.py:179-181,*/
+/* image_filtering.py:117-118).  OpenCV 4.1.0's generic 8u path restated:      */
+/* source coordinate fx = (dx + 0.5) * (src / dst) - 0.5, clamped to the image */
+/* (weight 0 on the missing neighbour); weights as 11-bit fixed point          */
+/* (saturate_cast<short>(w * 2048)); horizontal sums in int32; vertical:       */
+/* (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.             */
+/* ------------------------------------------------------------------------- */
+static void resize_axis(int src, int dst, int *idx, short *w)
+{
+    double scale = (double)src / dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= s0;
+        if (s0 < 0) { s0 = 0; f = 0.f; }
+        if (s0 >= src - 1) { s0 = src - 1; f = 0.f; }
+        idx[d] = s0;
+        w[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        w[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+
+ORC_API int orc_resize_linear_u8(const uint8_t *src, int H, int W, int ch, int dH, int dW, uint8_t *dst)
+{
+    int *xi = (int *)malloc(sizeof(int) * dW), *yi = (int *)malloc(sizeof(int) * dH);
+    short *xw = (short *)malloc(sizeof(short) * 2 * dW), *yw = (short *)malloc(sizeof(short) * 2 * dH);
+    if (!xi || !yi || !xw || !yw) { free(xi); free(yi); free(xw); free(yw); return -2; }
+    resize_axis(W, dW, xi, xw);
+    resize_axis(H, dH, yi, yw);
+    for (int y = 0; y < dH; ++y) {
+        int y0 = yi[y], y1 = y0 + 1 < H ? y0 + 1 : y0;
+        for (int x = 0; x < dW; ++x) {
+            int x0 = xi[x], x1 = x0 + 1 < W ? x0 + 1 : x0;
+            for (int c = 0; c < ch; ++c) {
+                int s0 = src[((int64_t)y0 * W + x0) * ch + c] * xw[2 * x] + src[((int64_t)y0 * W + x1) * ch + c] * xw[2 * x + 1];
+                int s1 = src[((int64_t)y1 * W + x0) * ch + c] * xw[2 * x] + src[((int64_t)y1 * W + x1) * ch + c] * xw[2 * x + 1];
+                int v = (((yw[2 * y] * (s0 >> 4)) >> 16) + ((yw[2 * y + 1] * (s1 >> 4)) >> 16) + 2) >> 2;
+                dst[((int64_t)y * dW + x) * ch + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+    }
+    free(xi); free(yi); free(xw); free(yw);
     return 0;
 }
 

@@ -85,6 +85,8 @@ _SIGS = {
     "swk_bilateral_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p]),
     "swk_thresh_tozero_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "swk_grey_open3x3_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "swk_grey_open_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p]),
+    "swk_resize_linear_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6 + [ctypes.c_void_p]),
     "swk_ccl_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_regionprops_u8": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_classifier_input": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
@@ -502,6 +504,23 @@ class Context:
         out = np.empty_like(s)
         self._check(self._lib.swk_grey_open3x3_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], _ptr(out)))
         return out[0] if single else out
+
+    def grey_open_u8(self, src, size):
+        """scipy.ndimage.grey_opening(size=(kh, kw)) on u8 images, any window."""
+        s, single = self._planes(src)
+        out = np.empty_like(s)
+        self._check(self._lib.swk_grey_open_u8(self._h, _ptr(s), s.shape[0], s.shape[1], s.shape[2], int(size[0]), int(size[1]), _ptr(out)))
+        return out[0] if single else out
+
+    def resize_linear_u8(self, frame, dsize):
+        """cv2.resize(frame, dsize=(width, height)) (INTER_LINEAR) for one (H, W[, C]) u8 frame."""
+        f = np.ascontiguousarray(frame, np.uint8)
+        H, W = f.shape[:2]
+        ch = 1 if f.ndim == 2 else f.shape[2]
+        dW, dH = int(dsize[0]), int(dsize[1])
+        out = np.empty((dH, dW) + ((ch,) if f.ndim == 3 else ()), np.uint8)
+        self._check(self._lib.swk_resize_linear_u8(self._h, _ptr(f), 1, H, W, ch, dH, dW, _ptr(out)))
+        return out
 
     def ccl_u8(self, src, connectivity=8, label_order=ORDER_BLOCK2X2):
         s, single = self._planes(src)

@@ -254,6 +254,75 @@ __global__ __launch_bounds__(256) void k_open3x3(const uint8_t *__restrict__ src
     }
 }
 
+// Flat grey erosion / dilation with any window (scipy.ndimage.grey_opening(size=(kh, kw)), border mode 'reflect': d c b a | a b c d):
+// erosion looks at offsets -k/2 .. k-1-k/2, dilation at the mirrored ones -- the same for an odd size, one apart for an even one (scipy
+// negates the origin for the dilation and shifts it by one when the size is even).  The reference only ever asks for (3, 3)
+// (data_structures.py:202), which the tiled kernels above serve; this one is the stage function's general case: one thread per
+// pixel straight from global memory (a frame's window rows sit in L2).
+__device__ __forceinline__ int reflect_index(int p, int len)
+{
+    while (p < 0 || p >= len) p = p < 0 ? -p - 1 : 2 * len - 1 - p;
+    return p;
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void k_flat_minmax(const uint8_t *__restrict__ src, int H, int W, int kh, int kw, uint8_t *__restrict__ dst)
+{
+    const int f = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const uint8_t *img = src + (int64_t)f * H * W;
+    const int lo_r = IS_MAX ? -(kh - 1 - kh / 2) : -(kh / 2), hi_r = IS_MAX ? kh / 2 : kh - 1 - kh / 2;
+    const int lo_c = IS_MAX ? -(kw - 1 - kw / 2) : -(kw / 2), hi_c = IS_MAX ? kw / 2 : kw - 1 - kw / 2;
+    int acc = IS_MAX ? 0 : 255;
+    for (int i = lo_r; i <= hi_r; ++i) {
+        const uint8_t *row = img + (int64_t)reflect_index(r + i, H) * W;
+        for (int j = lo_c; j <= hi_c; ++j) {
+            const int v = row[reflect_index(c + j, W)];
+            acc = IS_MAX ? (v > acc ? v : acc) : (v < acc ? v : acc);
+        }
+    }
+    dst[((int64_t)f * H + r) * W + c] = (uint8_t)acc;
+}
+
+void launch_grey_open(hipStream_t s, const uint8_t *src, int F, int H, int W, int kh, int kw, uint8_t *tmp, uint8_t *dst)
+{
+    for (int f0 = 0; f0 < F; f0 += 32768) {
+        const int fc = F - f0 < 32768 ? F - f0 : 32768;
+        const dim3 grid((W + 63) / 64, (H + 3) / 4, fc);
+        const int64_t off = (int64_t)f0 * H * W;
+        hipLaunchKernelGGL(k_flat_minmax<false>, grid, dim3(256), 0, s, src + off, H, W, kh, kw, tmp + off);
+        hipLaunchKernelGGL(k_flat_minmax<true>, grid, dim3(256), 0, s, tmp + off, H, W, kh, kw, dst + off);
+    }
+}
+
+// resize_frame (image_filtering.py:206-212): cv2.resize(frame, (w, h)) = INTER_LINEAR on 8-bit pixels, OpenCV 4.1.0's generic 8u
+// arithmetic restated (PARITY UNPINNED; dead code in the reference -- both call sites are commented out): per axis the source
+// coordinate (d + 0.5) * src / dst - 0.5 in float32, clamped to the image with weight 0 on the missing neighbour; weights as 11-bit
+// fixed point; horizontal sums in int32; vertical (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  The per-axis
+// tables (index, two weights) are made by the host.
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t *__restrict__ src, int H, int W, int ch, int dH, int dW,
+                                                          const int *__restrict__ xi, const short *__restrict__ xw,
+                                                          const int *__restrict__ yi, const short *__restrict__ yw, uint8_t *__restrict__ dst)
+{
+    const int f = blockIdx.z, x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= dH || x >= dW) return;
+    const uint8_t *img = src + (int64_t)f * H * W * ch;
+    const int y0 = yi[y], y1 = y0 + 1 < H ? y0 + 1 : y0, x0 = xi[x], x1 = x0 + 1 < W ? x0 + 1 : x0;
+    const int a0 = xw[2 * x], a1 = xw[2 * x + 1], b0 = yw[2 * y], b1 = yw[2 * y + 1];
+    for (int c = 0; c < ch; ++c) {
+        const int s0 = img[((int64_t)y0 * W + x0) * ch + c] * a0 + img[((int64_t)y0 * W + x1) * ch + c] * a1;
+        const int s1 = img[((int64_t)y1 * W + x0) * ch + c] * a0 + img[((int64_t)y1 * W + x1) * ch + c] * a1;
+        const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        dst[(((int64_t)f * dH + y) * dW + x) * ch + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+void launch_resize_linear(hipStream_t s, const uint8_t *src, int F, int H, int W, int ch, int dH, int dW, const int *xi, const short *xw,
+                          const int *yi, const short *yw, uint8_t *dst)
+{
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3((dW + 63) / 64, (dH + 3) / 4, F), dim3(256), 0, s, src, H, W, ch, dH, dW, xi, xw, yi, yw, dst);
+}
+
 void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint8_t *dst)
 {
     for (int f0 = 0; f0 < F; f0 += 32768) {

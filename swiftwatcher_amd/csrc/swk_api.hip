@@ -961,6 +961,60 @@ int32_t swk_grey_open3x3_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int
     return sync(ctx);
 }
 
+int32_t swk_grey_open_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t kh, int32_t kw, uint8_t *dst)
+{
+    if (!ctx || !src || !dst || count < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || kh > 255 || kw > 255) return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)count * H * W;
+    uint8_t *din, *dout, *dtmp;
+    NEED(ctx, SL_TMP_IN, px, din);
+    NEED(ctx, SL_TMP_OUT, px, dout);
+    NEED(ctx, SL_REDO_S2, px, dtmp);          // (a scratch plane: the rerun slots are idle outside run_ialm)
+    HIPCHK(ctx, hipMemcpyAsync(din, src, px, hipMemcpyHostToDevice, ctx->stream));
+    launch_grey_open(ctx->stream, din, count, H, W, kh, kw, dtmp, dout);
+    HIPCHK(ctx, hipMemcpyAsync(dst, dout, px, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+int32_t swk_resize_linear_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t channels, int32_t dH, int32_t dW,
+                             uint8_t *dst)
+{
+    if (!ctx || !src || !dst || count < 1 || H < 1 || W < 1 || dH < 1 || dW < 1 || channels < 1 || channels > 4)
+        return fail(ctx, SWK_ERR_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // per-axis tables (OpenCV 4.1.0 resizeGeneric_ for INTER_LINEAR, 8u: float32 coordinates, 11-bit weights)
+    std::vector<int> idx((size_t)dW + dH);
+    std::vector<short> wts(2 * ((size_t)dW + dH));
+    auto axis = [](int srcn, int dstn, int *ix, short *w) {
+        const double scale = (double)srcn / dstn;
+        for (int d = 0; d < dstn; ++d) {
+            float f = (float)((d + 0.5) * scale - 0.5);
+            int s0 = (int)floorf(f);
+            f -= s0;
+            if (s0 < 0) { s0 = 0; f = 0.f; }
+            if (s0 >= srcn - 1) { s0 = srcn - 1; f = 0.f; }
+            ix[d] = s0;
+            w[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+            w[2 * d + 1] = (short)lrintf(f * 2048.f);
+        }
+    };
+    axis(W, dW, idx.data(), wts.data());
+    axis(H, dH, idx.data() + dW, wts.data() + 2 * dW);
+    const size_t in_b = (size_t)count * H * W * channels, out_b = (size_t)count * dH * dW * channels;
+    uint8_t *din, *dout;
+    int *dix; short *dw;
+    NEED(ctx, SL_TMP_IN, in_b, din);
+    NEED(ctx, SL_TMP_OUT, out_b, dout);
+    NEED(ctx, SL_REDO_S2, idx.size() * 4 + wts.size() * 2, dix);
+    dw = (short *)(dix + idx.size());
+    HIPCHK(ctx, hipMemcpyAsync(din, src, in_b, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dix, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dw, wts.data(), wts.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    launch_resize_linear(ctx->stream, din, count, H, W, channels, dH, dW, dix, dw, dix + dW, dw + 2 * dW, dout);
+    HIPCHK(ctx, hipMemcpyAsync(dst, dout, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);          // (synchronous: idx / wts live on this stack frame)
+}
+
 int32_t swk_ccl_u8(swk_ctx *ctx, const uint8_t *src, int32_t count, int32_t H, int32_t W, int32_t connectivity,
                    int32_t label_order, int32_t *labels, int32_t *ncomp)
 {

@@ -146,6 +146,11 @@ void launch_bilateral(hipStream_t s, const uint8_t *src, int F, int H, int W, co
                       int use_fma, uint8_t *dst);
 void launch_thresh(hipStream_t s, const uint8_t *src, int64_t count, int thresh, uint8_t *dst);
 void launch_open3x3(hipStream_t s, const uint8_t *src, int F, int H, int W, uint8_t *dst);
+// any window (scipy's placement of even ones); tmp: F x H x W bytes for the eroded image
+void launch_grey_open(hipStream_t s, const uint8_t *src, int F, int H, int W, int kh, int kw, uint8_t *tmp, uint8_t *dst);
+// cv2.resize INTER_LINEAR on 8-bit pixels; per-axis index / weight tables made by the host
+void launch_resize_linear(hipStream_t s, const uint8_t *src, int F, int H, int W, int ch, int dH, int dW, const int *xi, const short *xw,
+                          const int *yi, const short *yw, uint8_t *dst);
 // fused bilateral (radius 3) + to-zero threshold + 3x3 opening; optional intermediates
 void launch_filter_fused(hipStream_t s, const uint8_t *src, int F, int H, int W, const BilateralTables &t,
                          int use_fma, int thresh, uint8_t *bil_out, uint8_t *thr_out, uint8_t *open_out);

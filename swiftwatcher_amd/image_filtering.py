@@ -147,11 +147,17 @@ def thresh_to_zero(frame, thresh):
 
 
 def grayscale_opening(frame, SE):
-    """image_filtering.py:319-322.  Only the (3, 3) window the reference uses
-    (data_structures.py:202) is implemented on the GPU."""
-    if tuple(SE) != (3, 3):
-        raise NotImplementedError("grey opening is implemented for SE=(3, 3) only")
-    return _ctx().grey_open3x3_u8(frame)
+    """image_filtering.py:319-322: scipy.ndimage.grey_opening(frame, size=SE).  (3, 3) -- the window the reference uses
+    (data_structures.py:202) -- runs on the tiled kernel, any other window on the general one."""
+    if tuple(SE) == (3, 3):
+        return _ctx().grey_open3x3_u8(frame)
+    return _ctx().grey_open_u8(frame, tuple(SE))
+
+
+def resize_frame(frame, dimensions):
+    """image_filtering.py:206-212: cv2.resize(frame, dimensions) with dimensions = (width, height).  The reference's two call
+    sites are commented out (data_structures.py:179-181, image_filtering.py:117-118); PARITY UNPINNED (cv2)."""
+    return _ctx().resize_linear_u8(frame, dimensions)
 
 
 def cc_labeling(frame, connectivity=None, effective_connectivity=8, label_order=_lib.ORDER_BLOCK2X2):

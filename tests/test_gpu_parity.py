@@ -89,6 +89,42 @@ def test_grey_opening_golden_and_random(ctx, orc, golden_dir):
         np.testing.assert_array_equal(ctx.grey_open3x3_u8(im), orc.grey_open_u8(im))
 
 
+def test_grey_opening_with_other_windows(ctx, orc, golden_dir):
+    """grayscale_opening(frame, SE) takes any SE in the reference (image_filtering.py:319-322); the loop only asks for (3, 3).  The general
+    kernel against fixtures made by the reference's own function (scipy: odd, even, rectangular and 1-wide windows, an image smaller
+    than the window) and against the oracle on random images; (3, 3) through it equals the tiled kernel."""
+    from swiftwatcher_amd import image_filtering as img
+    g = np.load(os.path.join(golden_dir, "grey_opening_windows.npz"))
+    for i in range(int(g["count"])):
+        for kh, kw in g["sizes"]:
+            np.testing.assert_array_equal(ctx.grey_open_u8(g["in%d" % i], (kh, kw)), g["out%d_%dx%d" % (i, kh, kw)], err_msg="%d %dx%d" % (i, kh, kw))
+    rng = np.random.default_rng(44)
+    for shape, size in [((212, 424), (5, 5)), ((33, 65), (4, 7)), ((64, 64), (11, 2)), ((3, 3), (5, 5)), ((50, 70), (3, 3))]:
+        im = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        np.testing.assert_array_equal(ctx.grey_open_u8(im, size), orc.grey_open_u8(im, size), err_msg=str(size))
+    im = rng.integers(0, 256, size=(90, 130), dtype=np.uint8)
+    np.testing.assert_array_equal(ctx.grey_open_u8(im, (3, 3)), ctx.grey_open3x3_u8(im))
+    np.testing.assert_array_equal(img.grayscale_opening(im, (5, 3)), orc.grey_open_u8(im, (5, 3)))
+
+
+def test_resize_frame(ctx, orc):
+    """resize_frame (image_filtering.py:206-212: cv2.resize, INTER_LINEAR; dead code in the reference, PARITY UNPINNED): the kernel against
+    the C restatement of OpenCV 4.1.0's 8-bit arithmetic -- down, up, one axis only, grey and BGR -- and two properties the arithmetic
+    has whatever the rounding: a constant image stays constant, the same size is the identity."""
+    from swiftwatcher_amd import image_filtering as img
+    rng = np.random.default_rng(45)
+    for shape, dsize in [((212, 424, 3), (300, 150)), ((107, 214), (300, 150)), ((40, 60, 3), (60, 40)), ((40, 60, 3), (121, 77)),
+                         ((5, 7), (3, 2)), ((33, 65, 3), (65, 20))]:
+        im = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        got = img.resize_frame(im, dsize)
+        assert got.shape[:2] == (dsize[1], dsize[0])
+        np.testing.assert_array_equal(got, orc.resize_linear_u8(im, dsize), err_msg=str((shape, dsize)))
+    flat = np.full((37, 53, 3), 171, np.uint8)
+    assert (ctx.resize_linear_u8(flat, (300, 150)) == 171).all()
+    im = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(ctx.resize_linear_u8(im, (53, 37)), im)
+
+
 @pytest.mark.parametrize("conn,order", [(8, 1), (8, 0), (4, 0), (4, 1)])
 def test_ccl(ctx, orc, conn, order):
     rng = np.random.default_rng(5)
@@ -333,25 +369,27 @@ def test_sparse_store_speculation_never_changes_results(orc):
 
 
 def test_only_the_windows_whose_guess_failed_run_again(orc):
-    """Eight windows of two kinds in one call, the stopping norm formed every other iteration to the very end
-    (swk_set_norm_speculation(1e-9)): a window stops on a formed norm or on an unformed one by the parity of its iteration count (23 for
-    the one kind, 22 for the other), so SOME windows fail the guess.  Those -- and only those -- are run again (one nested call, guesses off); every window's iteration
-    count, sparse image, labels and region records are the oracle's, the untouched windows' included."""
+    """Eight windows of two kinds in one call.  The stores of the sparse image start once ||Z|| < factor x tol x ||X||
+    (swk_set_sparse_speculation); the answer is the image the pass BEFORE the last wrote, so a window fails the guess when its ratio two
+    iterations before the end was still above the factor.  The reference's ratios there (numpy, tol units): 1.72-1.76 for the one kind
+    (23 iterations), 2.47-2.55 for the other (22: 12 large birds, noisy sensor) -- with a factor of 2.1 exactly the second kind fails.
+    Those four windows -- and only those -- run again (one nested call, guesses off); every window's iteration count, sparse image,
+    labels and region records are the oracle's, the untouched windows' included."""
     from swiftwatcher_amd import _lib, synthetic
     n, Hc, Wc, nwin = 21, 64, 96, 8
-    # two kinds of scene, alternating: the reference needs 23 iterations for the one, 22 for the other (12 large birds, noisy sensor)
     kinds = (dict(birds=3, noise=2.0, bird_len=(8, 14), bird_wid=(3, 6)), dict(birds=12, noise=6.0, bird_len=(20, 30), bird_wid=(10, 14)))
     roi = np.concatenate([synthetic.roi_window(4100 + 7 * w, n, Hc, Wc, **kinds[w % 2]) for w in range(nwin)])
     c = _lib.Context(0)
-    c.set_norm_speculation(1e-9)
+    c.set_norm_speculation(0.0)
+    c.set_sparse_speculation(2.1)
     res = c.batch_run(roi, nwin, n, stages=("rpca", "labels"))
     redone = c.redo_windows
-    assert c.redo_batches == (1 if redone else 0) and redone <= nwin
-    c.set_norm_speculation(0.0)
+    assert c.redo_batches == 1 and redone == 4, (c.redo_batches, redone)
     c.set_sparse_speculation(0.0)
     plain = c.batch_run(roi, nwin, n, stages=("rpca", "labels"))
     assert c.redo_windows == redone
     np.testing.assert_array_equal(res["iters"], plain["iters"])
+    assert [int(i) for i in res["iters"]] == [23, 22] * 4
     for key in ("rpca", "labels", "nseg"):
         np.testing.assert_array_equal(res[key], plain[key], err_msg=key)
     assert res["segs"].tobytes() == plain["segs"].tobytes()
@@ -359,9 +397,6 @@ def test_only_the_windows_whose_guess_failed_run_again(orc):
         ref = orc.window(np.ascontiguousarray(roi[w * n:(w + 1) * n]))
         np.testing.assert_array_equal(res["rpca"][w * n:(w + 1) * n], ref["rpca"], err_msg="window %d" % w)
         np.testing.assert_array_equal(res["labels"][w * n:(w + 1) * n], ref["labels"])
-    # the two kinds stop on different parities: a proper subset ran again
-    assert sorted(set(int(i) for i in res["iters"])) == [22, 23]
-    assert 0 < redone < nwin, (redone, [int(i) for i in res["iters"]])
     c.close()
 
 

@@ -221,3 +221,21 @@ def test_bilateral_spec():
             v = int(img[7 + i, 8 + j]); w = np.float32(sw * cw[abs(v - 0)])
             s = np.float32(s + np.float32(np.float32(v) * w)); ws = np.float32(ws + w)
     assert out[7, 8] == int(np.rint(np.float32(s / ws)))
+
+
+def test_grey_opening_other_windows_fixture(golden_dir):
+    """Round 4: windows other than (3, 3), even sizes included, made by the reference's own grayscale_opening (scipy)."""
+    g = _load(golden_dir, "grey_opening_windows.npz")
+    for i in range(int(g["count"])):
+        for kh, kw in g["sizes"]:
+            np.testing.assert_array_equal(orc.grey_open_u8(g["in%d" % i], (int(kh), int(kw))), g["out%d_%dx%d" % (i, kh, kw)])
+
+
+def test_resize_restatement_properties():
+    """cv2.resize is installed nowhere (PARITY UNPINNED): what the restated arithmetic guarantees by itself."""
+    rng = np.random.default_rng(3)
+    im = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(orc.resize_linear_u8(im, (53, 37)), im)
+    assert (orc.resize_linear_u8(np.full((20, 30), 99, np.uint8), (300, 150)) == 99).all()
+    up = orc.resize_linear_u8(im[:, :, 0], (106, 74)).astype(int)
+    assert up.min() >= im[:, :, 0].min() and up.max() <= im[:, :, 0].max()
