@@ -73,8 +73,9 @@ class PresegmentingReader:
     identical (windows are independent).  Needs to know what segment_queue will be asked: crop_region, min_seg_size, queue_size (a ROI
     stream carries the first two in its header).  The stage images of such a window are produced only if somebody reads them."""
 
-    def __init__(self, reader, crop_region=None, queue_size=21, windows=8, min_seg_size=None, device=0, params=None):
+    def __init__(self, reader, crop_region=None, queue_size=21, windows=8, min_seg_size=None, device=0, params=None, classifier=None):
         import collections
+        import weakref
         self.reader = reader
         self.crop_region = crop_region if crop_region is not None else reader.crop_region
         self.min_seg_size = tuple(min_seg_size if min_seg_size is not None else getattr(reader, "min_seg_size", (24, 24)))
@@ -83,7 +84,11 @@ class PresegmentingReader:
             reader.ahead = max(reader.ahead, self.windows)
         self._ready = collections.deque()            # windows segmented and not yet handed out: (frames, numbers, stamps, counters)
         self._job = None                             # the batch being read and segmented: (thread event with .result / .error)
-        self._classifier_hint = None                 # set by the batch whose scores a classifier asked for (data_structures.WindowBatch)
+        # the classifier whose scoring is started with every batch's segmentation: handed in (classifier=..., or by the counting loop:
+        # pipeline.swift_counting_algorithm sets it), else learned from the first batch whose scores a classifier asks for
+        # (data_structures.WindowBatch) -- which never happens in time when a video starts with frames without segments (the
+        # classifier returns early on an empty list): such a video then scored frame by frame until a batch's first window had some
+        self._classifier_hint = weakref.ref(classifier) if classifier is not None else None
         self._delivered = 0
         self._handed = collections.deque()           # keys of the windows handed out last (their entries go when the caller has moved on)
         self._exhausted = False

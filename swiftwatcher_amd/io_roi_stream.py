@@ -33,6 +33,7 @@ import numpy as np
 from . import _lib
 
 MAGIC = b"SWKROI1\n"
+_PIXELS_LOCK = threading.Lock()          # RoiFrame.__getitem__ against RoiFrame.detach (two threads of one reader's frames)
 
 
 def margin_rect(frame_hw, crop_region, min_seg_size=(24, 24)):
@@ -49,12 +50,13 @@ class RoiFrame:
     """The stored rectangle of one frame, indexed in FULL-frame coordinates.  frame[ya:yb, xa:xb] (the two slices crop_frame and
     extract_segment_images make) is translated and clipped like numpy clips a slice at the full frame's edges; anything else of
     ndarray's interface is not offered -- the counting loop does not use it."""
-    __slots__ = ("roi", "origin", "shape", "dtype", "ndim", "block", "slot", "__weakref__")
+    __slots__ = ("roi", "origin", "shape", "dtype", "ndim", "block", "slot", "recycled", "__weakref__")
 
     def __init__(self, roi, origin, full_shape, block=None, slot=-1):
         self.roi, self.origin, self.shape = roi, origin, tuple(full_shape)
         self.dtype, self.ndim = roi.dtype, len(self.shape)
         self.block, self.slot = block, slot
+        self.recycled = False          # True once the pixels sit in a buffer that returns to a reader's spare list with this frame
 
     def __getitem__(self, key):
         if not (isinstance(key, tuple) and len(key) >= 2 and isinstance(key[0], slice) and isinstance(key[1], slice)):
@@ -64,26 +66,38 @@ class RoiFrame:
         xs, xe, _ = key[1].indices(self.shape[1])
         if key[0].step not in (None, 1) or key[1].step not in (None, 1):
             raise TypeError("strided access to a RoiFrame")
-        h, w = self.roi.shape[:2]
+        h, w = self.roi.shape[:2]          # (the stored rectangle's size never changes)
         if ys < oy or xs < ox or ye > oy + h or xe > ox + w:
             if ye > ys and xe > xs:
                 raise IndexError("rows %d:%d, columns %d:%d leave the stored rectangle (rows %d:%d, columns %d:%d)"
                                  % (ys, ye, xs, xe, oy, oy + h, ox, ox + w))
-        out = self.roi[max(ys - oy, 0):max(ye - oy, 0), max(xs - ox, 0):max(xe - ox, 0)]
-        if len(key) > 2:
-            out = out[(slice(None), slice(None)) + tuple(key[2:])]
-        # pixels that live in a reader's block are handed out as a copy: the block is reused two windows later
-        return out.copy() if self.block is not None else out
+        # Pixels that live in a reader's block are copied out UNDER THE LOCK detach() takes: the reader's read-ahead thread gives a
+        # frame private pixels (and then overwrites the block) while the counting loop's thread may be slicing it -- without the
+        # lock a slice could pair the old pixels with the cleared `block` (an uncopied view of a block about to be overwritten) or
+        # copy a block that is being refilled.
+        with _PIXELS_LOCK:
+            roi, block = self.roi, self.block
+            out = roi[max(ys - oy, 0):max(ye - oy, 0), max(xs - ox, 0):max(xe - ox, 0)]
+            if len(key) > 2:
+                out = out[(slice(None), slice(None)) + tuple(key[2:])]
+            if block is not None:
+                return out.copy()
+        # pixels that live in a reader's block are handed out as a copy: the block is reused a few windows later.  Private pixels that
+        # go back to the reader's spare list when the frame dies (detach(spare)) are copied too: a view kept beyond the frame's life
+        # would change content when the buffer is reused
+        return out.copy() if self.recycled else out
 
     def detach(self, spare=None):
         """Private copy of the pixels: the block they live in is about to be reused.  spare: a list of arrays of the right shape that
         earlier detached frames have given back (fresh pages are expensive; a long video recycles a handful of buffers)."""
         buf = spare.pop() if spare else np.empty_like(self.roi)
-        np.copyto(buf, self.roi)
-        self.roi = buf
-        self.block, self.slot = None, -1
-        if spare is not None:
-            weakref.finalize(self, spare.append, buf)
+        with _PIXELS_LOCK:
+            np.copyto(buf, self.roi)
+            if spare is not None:
+                self.recycled = True
+                weakref.finalize(self, spare.append, buf)
+            self.roi = buf
+            self.block, self.slot = None, -1
 
     def as_full_frame(self, fill=128):
         """A full-size ndarray with the stored rectangle pasted in (ROI-mask generation reads the first frame's crop region)."""

@@ -24,6 +24,9 @@ def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size
     if crop_region is None or roi_mask is None:
         raise ValueError("either corners or crop_region + roi_mask are needed")
     tracker = SegmentTracker(roi_mask)
+    if classifier is not None and getattr(reader, "_classifier_hint", False) is None:
+        import weakref
+        reader._classifier_hint = weakref.ref(classifier)          # a reader that segments ahead scores every batch for this classifier
     if windows_per_call > 1:
         if hasattr(reader, "ahead"):                 # a reader that reads ahead (io_roi_stream): as far as one GPU call takes
             reader.ahead = max(reader.ahead, windows_per_call)

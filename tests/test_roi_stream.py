@@ -244,3 +244,40 @@ def test_presegmenting_reader_leaves_the_loop_and_its_results_unchanged(tmp_path
         assert [(s.label, s.bbox, s.centroid) for s in f2.segments] == [(s.label, s.bbox, s.centroid) for s in f3.segments]
     reader.close()
     assert not ds.PRESEGMENTED
+
+
+@pytest.mark.gpu
+def test_presegmenting_reader_scores_batches_when_the_video_starts_empty():
+    """A chimney video starts with empty sky: the first window has no segment, so `classifier(frame.segments)` returns early for every
+    frame of it and never asks for the batch's scores.  The reader that segments ahead must not depend on being asked: the counting
+    loop hands it the classifier, every batch is scored with its segmentation, and NO frame falls back to scoring its segment images
+    one window at a time.  Events equal the plain loop's."""
+    from swiftwatcher_amd import synthetic, pipeline
+    from swiftwatcher_amd import image_filtering as img
+    from swiftwatcher_amd.io_frames import PresegmentingReader
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref
+    from helpers import event_signature
+    corners = [(250, 200), (420, 201)]
+    crop_region = img.generate_crop_region(corners)
+    (x0, y0), (x1, y1) = crop_region
+    busy = synthetic.full_frames(94, 21 * 5, crop_region, frame_hw=(360, 640), birds=8, bird_len=(10, 16), bird_wid=(5, 8))[::-1]
+    empty = synthetic.full_frames(95, 21, crop_region, frame_hw=(360, 640), birds=0)[::-1]
+    frames = list(empty) + list(busy)
+    roi_mask = np.zeros((y1 - y0, x1 - x0), np.uint8)
+    roi_mask[(y1 - y0) // 2:, 20:-20] = 255
+    plain_no_clf = pipeline.swift_counting_algorithm(ArrayReader(frames), crop_region, roi_mask)
+    crops = [s.segment_image for ev in plain_no_clf for s in ev][:64]
+    assert crops
+    sd = classifier_ref.calibrate_head(classifier_ref.random_state_dict(11), crops)
+    clf = SegmentClassifier.from_state_dict(sd)
+    plain = pipeline.swift_counting_algorithm(ArrayReader(frames), crop_region, roi_mask, classifier=clf)
+    batch_calls, image_calls = [], []
+    inner_b, inner_s = clf.predict_last_batch, clf.scores
+    clf.predict_last_batch = lambda *a, **k: (batch_calls.append(1), inner_b(*a, **k))[1]
+    clf.scores = lambda images: (image_calls.append(len(images)), inner_s(images))[1]
+    pre = PresegmentingReader(ArrayReader(frames), crop_region, windows=3)
+    events = pipeline.swift_counting_algorithm(pre, crop_region, roi_mask, classifier=clf)
+    assert event_signature(events) == event_signature(plain) and len(events) >= 1
+    assert not image_calls, image_calls              # nothing was scored from segment images, frame by frame
+    assert 1 <= len(batch_calls) <= 3                # 6 queue-fuls (+ the padded one) in batches of three: one scoring per batch that has segments
