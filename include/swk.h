@@ -284,23 +284,6 @@ int32_t swk_nhwc_conv7x7s2_bias_relu(void *stream, const float *src, int32_t n, 
 int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t crop_y,
                                          int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias, int32_t cout,
                                          float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
-/* Fire -> Fire hand-over without the expand1x1 tensor (csrc/cnn_expand_sq.hip).  The squeeze of the next Fire is linear in its input
- * before bias and ReLU, so its sum splits by producer:  S' = relu(Wq1 E1 + Wq3 E3 + bq)  with  E1 = relu(W1 s + b1).
- * expand1x1_squeeze_partial:  dst[n][off_y+y][off_x+x][so] = sum_c wq[so][c] * max(sum_ci src[n][crop_y+y][crop_x+x][ci] * w1[c][ci] + b1[c], 0)
- *   for so < sq_out (<= 64), c < c1: two chained products per pixel, the expand1x1 channels never reach memory.  src [n][sh][sw][cin]
- *   with (cin, c1) = (16, 64), (32, 128) or (48, 192); wq = the next squeeze's weight [sq_out][wq_stride] (its first c1 columns are
- *   used); dst [n][dH][dW][dC] (no bias, no ReLU: partial sums).
- * conv1x1_add_bias_relu_place:  dst[n][off_y+y][off_x+x][co] = max(sum_ci src[n][crop_y+y][crop_x+x][ci] * weight[co][ci] + add[n][y][x][co]
- *   + bias[co], 0):  the next squeeze over the expand3x3 half alone -- src has src_c channels per pixel of which the FIRST cin are
- *   read (pass the pointer to the half's first channel), weight [cout][cin] dense, add [n][h][w][cout] dense, cout <= 64. */
-int32_t swk_nhwc_expand1x1_squeeze_partial(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t crop_y,
-                                           int32_t crop_x, int32_t h, int32_t w, const float *w1, const float *b1, int32_t c1,
-                                           const float *wq, int32_t wq_stride, int32_t sq_out, float *dst, int32_t dH, int32_t dW, int32_t dC,
-                                           int32_t off_y, int32_t off_x);
-int32_t swk_nhwc_conv1x1_add_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t src_c,
-                                             int32_t crop_y, int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias,
-                                             int32_t cout, const float *add, float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y,
-                                             int32_t off_x);
 
 /* maxpool3s2 + conv1x1_bias_relu_place as ONE kernel (a MaxPool2d(3, 2) followed by a Fire module's squeeze: the pooled tensor never
  * goes to memory): src [n][t][t][cin] (cin a multiple of 32), pooled size p = (t - 3) / 2 + 1 (p * p <= 96), weight [cout][cin] with

@@ -33,13 +33,11 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // CS = column splits: CS waves share a row tile, each computing NBLK / CS of its 32-channel column blocks (they load the same
 // activations; the accumulators of a wave shrink to 16 NBLK / CS registers).  NWV = waves per workgroup: 16 (one workgroup per
 // CU whatever its weight matrix takes of the LDS, four waves per SIMD at <= 128 registers) or 8 (two per SIMD).
-// ADD: the sum starts from a second tensor, add[n][y][x][co] ([n][h][w][cout] dense) -- the partial squeeze sums of cnn_expand_sq.hip;
-// src_c = channels per pixel of the source tensor (>= cin: the kernel may read a leading channel range of a wider tensor).
-template <int NBLK, int KC, int D, int CS, int NWV, bool ADD = false>
+template <int NBLK, int KC, int D, int CS, int NWV>
 __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__restrict__ src, int64_t rows, int sh, int sw, int cin, int crop_y,
                                                             int crop_x, int h, int w, const float *__restrict__ wgt, const float *__restrict__ bias,
                                                             int cout, float *__restrict__ dst, int dH, int dW, int dC, int off_y, int off_x, int c_off,
-                                                            FastDiv fhw, FastDiv fw, int src_c, const float *__restrict__ add)
+                                                            FastDiv fhw, FastDiv fw)
 {
     constexpr int NP = 32 * NBLK, PITCH = NP + 1, KH = KC / 2, NV = KH / 4, NB = NBLK / CS, NT = 64 * NWV, SLOTS = NWV / CS;
     static_assert(NBLK % CS == 0 && NWV % CS == 0, "column splits");
@@ -51,7 +49,6 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__
     const int64_t ntiles = (rows + 31) >> 5, stride = (int64_t)gridDim.x * SLOTS;
     int64_t tile = (int64_t)blockIdx.x * SLOTS + wave / CS;
 
-    int64_t ao = 0, ao_next = 0;          // ADD: offset of the lane's pixel in the addend
     // source pointer and destination offset of this lane's pixel in a row tile (rows past the end repeat the last one)
     auto locate = [&](int64_t t, int64_t &ro) -> const float * {
         const unsigned m = (unsigned)t * 32u + (unsigned)r;          // rows < 2^31 (checked by the launcher): invariant-divisor division
@@ -60,15 +57,13 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__
         const unsigned b = fhw.div(mm), rem = mm - b * (unsigned)hw;
         const unsigned y = fw.div(rem), x = rem - y * (unsigned)w;
         ro = valid ? (((int64_t)b * dH + off_y + y) * dW + off_x + x) * (int64_t)dC + c_off + 32 * NB * cs : -1;
-        if (ADD) ao_next = (int64_t)mm * cout + 32 * NB * cs;
-        return src + (((int64_t)b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)src_c + KH * hh;
+        return src + (((int64_t)b * sh + crop_y + y) * sw + crop_x + x) * (int64_t)cin + KH * hh;
     };
     float4 a[D][NV];
     int64_t ro = -1, ro_next = -1;
     const float *p = src, *pn = src;
     if (tile < ntiles) {           // the first pieces leave before the weights are staged
         p = locate(tile, ro);
-        ao = ao_next;
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -139,37 +134,26 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1_relu_place(const float *__
                     if (32 * NB * cs + c + 4 * hh < cout) {
                         const float4 b4 = *(const float4 *)(lbias + 32 * NB * cs + c + 4 * hh);
                         float4 v;
-                        if (ADD) {
-                            const float4 p4 = *(const float4 *)(add + ao + c + 4 * hh);
-                            v.x = fmaxf((acc[nb][4 * g] + p4.x) + b4.x, 0.0f);
-                            v.y = fmaxf((acc[nb][4 * g + 1] + p4.y) + b4.y, 0.0f);
-                            v.z = fmaxf((acc[nb][4 * g + 2] + p4.z) + b4.z, 0.0f);
-                            v.w = fmaxf((acc[nb][4 * g + 3] + p4.w) + b4.w, 0.0f);
-                        } else {
-                            v.x = fmaxf(acc[nb][4 * g] + b4.x, 0.0f);
-                            v.y = fmaxf(acc[nb][4 * g + 1] + b4.y, 0.0f);
-                            v.z = fmaxf(acc[nb][4 * g + 2] + b4.z, 0.0f);
-                            v.w = fmaxf(acc[nb][4 * g + 3] + b4.w, 0.0f);
-                        }
+                        v.x = fmaxf(acc[nb][4 * g] + b4.x, 0.0f);
+                        v.y = fmaxf(acc[nb][4 * g + 1] + b4.y, 0.0f);
+                        v.z = fmaxf(acc[nb][4 * g + 2] + b4.z, 0.0f);
+                        v.w = fmaxf(acc[nb][4 * g + 3] + b4.w, 0.0f);
                         *(float4 *)(o + c) = v;
                     }
                 }
         }
         p = pn;
         ro = ro_next;
-        ao = ao_next;
     }
 }
 
-template <int NBLK, int KC, int D, int CS, int NWV, bool ADD = false>
+template <int NBLK, int KC, int D, int CS, int NWV>
 static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
-                            const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off,
-                            int src_c = 0, const float *add = nullptr)
+                            const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off)
 {
-    if (src_c <= 0) src_c = cin;
     const size_t lds = (size_t)(((cin * (32 * NBLK + 1) + 3) & ~3) + 32 * NBLK) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D, CS, NWV, ADD>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
+    if (!ensure_dyn_lds((const void *)k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>, 160 * 1024 - 256, attr_mask)) return SWK_ERR_HIP;
     if (lds > 160 * 1024 - 256 || rows > (int64_t)0x7fffff00) return SWK_ERR_CAPACITY;
     constexpr int SLOTS = NWV / CS;
     const int64_t ntiles = (rows + 31) / 32;
@@ -180,8 +164,8 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     const int64_t per_cu = by_lds < 1 ? 1 : (by_lds < by_waves ? by_lds : by_waves);
     const int64_t cap = 256 * per_cu;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D, CS, NWV, ADD>), dim3((unsigned)blocks), dim3(64 * NWV), lds, s, src, rows, sh, sw, cin, crop_y,
-                       crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off, FastDiv((unsigned)(h * w)), FastDiv((unsigned)w), src_c, add);
+    hipLaunchKernelGGL((k_conv1x1_relu_place<NBLK, KC, D, CS, NWV>), dim3((unsigned)blocks), dim3(64 * NWV), lds, s, src, rows, sh, sw, cin, crop_y,
+                       crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off, FastDiv((unsigned)(h * w)), FastDiv((unsigned)w));
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
@@ -227,21 +211,6 @@ static int launch_conv1x1(hipStream_t s, const float *src, int64_t rows, int sh,
 }
 #undef SWK_C1_ARGS
 
-// The squeeze of a Fire that follows a Fire, reading only the expand3x3 half of its input (cin = 64, 128, 192 of src_c = 2 cin channels per
-// pixel) and starting from the partial sums of the expand1x1 half (cnn_expand_sq.hip): the same kernel with the ADD epilogue.
-template <int NBLK>
-static int launch_conv1x1_add(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int src_c, int crop_y, int crop_x, int h, int w,
-                              const float *wgt, const float *bias, int cout, const float *add, float *dst, int dH, int dW, int dC, int off_y, int off_x)
-{
-    const int64_t ntiles = (rows + 31) / 32;
-    const int nwv = ntiles >= 16 * 160 ? 16 : ntiles >= 8 * 160 ? 8 : 4;
-#define SWK_C1A(NWV) launch_conv1x1_d<NBLK, 32, 1, 1, NWV, true>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, wgt, bias, cout, dst, dH, dW, dC, off_y, off_x, 0, src_c, add)
-    if (nwv == 16) return SWK_C1A(16);
-    if (nwv == 8) return SWK_C1A(8);
-    return SWK_C1A(4);
-#undef SWK_C1A
-}
-
 }  // namespace swk
 
 #pragma GCC visibility push(default)
@@ -268,23 +237,6 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     case 8: return launch_conv1x1<8>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     default: return SWK_ERR_ARG;          // 5 and 7 blocks (129..160, 193..224 channels) do not occur in SqueezeNet-1.0
     }
-}
-
-int32_t swk_nhwc_conv1x1_add_bias_relu_place(void *stream, const float *src, int32_t n, int32_t sh, int32_t sw, int32_t cin, int32_t src_c,
-                                             int32_t crop_y, int32_t crop_x, int32_t h, int32_t w, const float *weight, const float *bias,
-                                             int32_t cout, const float *add, float *dst, int32_t dH, int32_t dW, int32_t dC, int32_t off_y,
-                                             int32_t off_x)
-{
-    if (!src || !weight || !bias || !dst || !add || n < 1 || h < 1 || w < 1 || cin < 32 || (cin & 31) || cin > 1024 || src_c < cin || (src_c & 3) ||
-        cout < 4 || cout > 64 || (cout & 3) || (dC & 3) || (((uintptr_t)dst) & 15) || (((uintptr_t)add) & 15) ||
-        crop_y < 0 || crop_x < 0 || crop_y + h > sh || crop_x + w > sw || off_y < 0 || off_x < 0 || off_y + h > dH || off_x + w > dW ||
-        cout > dC || ((((uintptr_t)src) | ((uintptr_t)weight)) & 15))
-        return SWK_ERR_ARG;
-    using namespace swk;
-    const int64_t rows = (int64_t)n * h * w;
-    hipStream_t s = (hipStream_t)stream;
-    if (cout <= 32) return launch_conv1x1_add<1>(s, src, rows, sh, sw, cin, src_c, crop_y, crop_x, h, w, weight, bias, cout, add, dst, dH, dW, dC, off_y, off_x);
-    return launch_conv1x1_add<2>(s, src, rows, sh, sw, cin, src_c, crop_y, crop_x, h, w, weight, bias, cout, add, dst, dH, dW, dC, off_y, off_x);
 }
 
 // Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the 1x1

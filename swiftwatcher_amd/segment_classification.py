@@ -159,20 +159,6 @@ class CroppedSqueezeNet10:
                 if pad[0] or pad[1]:
                     sq = torch.nn.functional.pad(sq, (pad[0], pad[1], pad[0], pad[1]))
                 self.sq_bg.append(sq.contiguous())
-        # Fire -> Fire hand-overs (fire2 -> 3, 3 -> 4, 5 -> 6, 6 -> 7, 7 -> 8) without the expand1x1 tensor (csrc/cnn_expand_sq.hip): the next
-        # squeeze's sum over the expand1x1 channels is formed where those channels are made, P1 = Wq1 relu(W1 s + b1), and only its
-        # 16 .. 64 partial sums are stored.  Blank-image value of P1 over the next layer's square: the ring of the persistent buffers.
-        self.p1_bg = []
-        with torch.no_grad():
-            for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
-                nxt = self.plan[j + 1] if j + 1 < len(self.plan) else None
-                if kind == "fire" and nxt is not None and nxt[0] == "fire":
-                    _, nlayer, ntile, noff, nsz, _, _ = nxt
-                    c1 = layer.expand1x1.out_channels
-                    bg = ntile[:, :c1, noff:noff + nsz, noff:noff + nsz]
-                    self.p1_bg.append(torch.nn.functional.conv2d(bg, nlayer.squeeze.weight[:, :c1]).contiguous())
-                else:
-                    self.p1_bg.append(None)
         self._cap = 0
         self._buf = None
         # channels-last on the GPU: what the library's convolution kernels read and write
@@ -185,9 +171,6 @@ class CroppedSqueezeNet10:
         self.winograd = True
         # max-pool + the squeeze behind it as one kernel (csrc/cnn_poolsq.hip): the pooled tensor never goes to memory
         self.fuse_pool = os.environ.get("SWK_FUSE_POOL", "1") == "1"
-        # expand1x1 -> partial sums of the next squeeze as one kernel (csrc/cnn_expand_sq.hip): the expand1x1 tensor never goes to memory
-        self.fuse_expand = os.environ.get("SWK_FUSE_EXPAND", "1") == "1"
-        self._wq3 = {}
         self._w1 = None
         self._wt3 = {}
         self._ww3 = {}
@@ -252,8 +235,6 @@ class CroppedSqueezeNet10:
                 live.append(bg.expand(batch, -1, -1, -1).contiguous(memory_format=self.memory_format))
             else:
                 live.append(None)
-        # partial squeeze sums of the fused Fire -> Fire hand-overs: ring = the blank image's values, centre written per forward
-        self._p1 = [None if bg is None else bg.expand(batch, -1, -1, -1).contiguous(memory_format=self.memory_format) for bg in self.p1_bg]
         self._buf, self._cap = (bufs, live), batch
         self.version = getattr(self, "version", 0) + 1          # new addresses: captured graphs of the old ones are void
         return self._buf
@@ -333,27 +314,6 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_conv1x1_bias_relu_place failed (%d)" % rc)
 
-        def expand_partial(sq, crop, size, e1, nsq, dest, off):
-            """dest[.., off + y, off + x, :] = Wq[:, :c1] relu(W1 sq[crop + y, crop + x] + b1): the expand1x1 half of the next squeeze's sum"""
-            w1 = e1.weight.reshape(e1.out_channels, e1.in_channels)
-            wq = nsq.weight.reshape(nsq.out_channels, nsq.in_channels)
-            rc = lib.swk_nhwc_expand1x1_squeeze_partial(stream, sq.data_ptr(), k, sq.shape[2], sq.shape[3], sq.shape[1], crop, crop, size, size,
-                                                        w1.data_ptr(), e1.bias.data_ptr(), e1.out_channels, wq.data_ptr(), nsq.in_channels,
-                                                        nsq.out_channels, dest.data_ptr(), dest.shape[2], dest.shape[3], dest.shape[1], off, off)
-            if rc:
-                raise RuntimeError("swk_nhwc_expand1x1_squeeze_partial failed (%d)" % rc)
-
-        def squeeze_add(src, c1, size, j, conv, add, dest, off):
-            """the squeeze over the expand3x3 half of src (channels c1 ..) + the partial sums of the expand1x1 half"""
-            w3 = self._wq3.get(j)
-            if w3 is None:
-                w3 = self._wq3[j] = conv.weight.detach()[:, c1:].reshape(conv.out_channels, conv.in_channels - c1).contiguous()
-            rc = lib.swk_nhwc_conv1x1_add_bias_relu_place(stream, src.data_ptr() + 4 * c1, k, src.shape[2], src.shape[3], conv.in_channels - c1,
-                                                          src.shape[1], 0, 0, size, size, w3.data_ptr(), conv.bias.data_ptr(), conv.out_channels,
-                                                          add.data_ptr(), dest.data_ptr(), dest.shape[2], dest.shape[3], dest.shape[1], off, off)
-            if rc:
-                raise RuntimeError("swk_nhwc_conv1x1_add_bias_relu_place failed (%d)" % rc)
-
         def conv3x3(src, j, conv, dest, off, c_off):
             src = nhwc(src)
             cin, cout = conv.in_channels, conv.out_channels
@@ -417,7 +377,6 @@ class CroppedSqueezeNet10:
         if not fuse:
             pool(c1buf, x)
         pi = 0
-        partial = None                # (partial sums of the expand1x1 half, its channel count) when the last Fire handed over fused
         for j, (kind, layer, tile, off, n, pad, crop) in enumerate(self.plan):
             if kind == "pool":
                 x = aux["pool_out"][pi][rows]
@@ -441,20 +400,11 @@ class CroppedSqueezeNet10:
                     assert (to_pool.shape[2] - 3) // 2 + 1 == n
                     pool_squeeze(to_pool, layer.squeeze, sq, off)
                     to_pool = None
-                elif partial is not None:
-                    squeeze_add(x, partial[1], n, j, layer.squeeze, partial[0], sq, off)
-                    partial = None
                 else:
                     conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
                 # expand1x1 only where the squeeze output depends on the segment (n x n inside the cn x cn square: the ring keeps the
                 # blank image's values the buffers were created with)
-                if self.fuse_expand and self._p1[j] is not None and k * cn * cn < (1 << 31):
-                    # ... and when the next layer is a Fire, not as a tensor at all: its share of the next squeeze's sum instead
-                    p1 = self._p1[j][rows]
-                    expand_partial(sq, off, n, layer.expand1x1, self.plan[j + 1][1].squeeze, p1, off - c)
-                    partial = (p1, c1)
-                else:
-                    conv1x1(sq, off, n, layer.expand1x1, dest, doff + off - c, 0)
+                conv1x1(sq, off, n, layer.expand1x1, dest, doff + off - c, 0)
             else:
                 place(conv2d(x, layer.squeeze.weight, None), layer.squeeze.bias, sq, 0, n, off, 0)
                 e1 = conv2d(sq, layer.expand1x1.weight, None)

@@ -56,12 +56,6 @@ def describe(name, a):
         n, t, cin, cout = a[2], a[3], a[4], a[7]
         p = (t - 3) // 2 + 1
         return "p+1x1 %3d->%3d %2dx%2d" % (cin, cout, p, p), n * p * p * cin * cout, 4 * n * (t * t * cin + p * p * cout)
-    if name == "swk_nhwc_expand1x1_squeeze_partial":          # two chained products per pixel: cin -> c1 -> sq_out
-        n, cin, h, w, c1, so = a[2], a[5], a[8], a[9], a[12], a[15]
-        return "e1>sq %2d->%3d->%2d %2dx%2d" % (cin, c1, so, h, w), n * h * w * (cin * c1 + c1 * so), 4 * n * h * w * (cin + so)
-    if name == "swk_nhwc_conv1x1_add_bias_relu_place":
-        n, cin, h, w, cout = a[2], a[5], a[9], a[10], a[13]
-        return "1x1+ %3d->%3d %2dx%2d" % (cin, cout, h, w), n * h * w * cin * cout, 4 * n * h * w * (cin + 2 * cout)
     if name == "swk_nhwc_maxpool3s2":
         n, h, w, c = a[2], a[3], a[4], a[5]
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
