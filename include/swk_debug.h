@@ -55,6 +55,11 @@ int32_t swk_set_norm_speculation(swk_ctx *ctx, double factor);
  * swk_prof_guard_windows counts those windows. */
 int32_t swk_set_norm_guard(swk_ctx *ctx, double rel);
 int32_t swk_prof_guard_windows(swk_ctx *ctx, int64_t *windows);
+/* Diagnostic of the same decision: for every window of the last swk_batch_run / swk_ialm (up to cap) the ratio ||Z||_F / ||X||_F of its
+ * LAST stopping test (image_filtering.py:297) and, for the M-state pass, the bound on that number's relative error the band is held
+ * against (float32 sum over a binary16 copy of Y/mu: csrc/ialm_small_dev.h; the effective band is max(rel, 4 x bound) per window).
+ * Returns the number of windows of that batch (negative: error).  The A/Y-state pass forms the norm in float64: bound 0. */
+int32_t swk_last_stopping_norms(swk_ctx *ctx, double *ratio, double *err_bound, int32_t cap);
 /* M-state pass only: 1 (default) = statistics and the first iteration's Gram matrix come from one read of X on the
  * integer matrix cores wherever the first shrinkage provably removes nothing; 0 = always the f64 start pass. */
 int32_t swk_set_integer_start(swk_ctx *ctx, int32_t on);

@@ -97,6 +97,7 @@ _SIGS = {
     "swk_set_norm_speculation": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_set_norm_guard": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_guard_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "swk_last_stopping_norms": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "swk_set_start_refine": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_double]),
     "swk_prof_refined_windows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "swk_prof_pass_bytes_per_element": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -353,6 +354,14 @@ class Context:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         self._check(self._lib.swk_prof_refined_windows(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def last_stopping_norms(self, cap=4096):
+        """(ratio ||Z||_F / ||X||_F of the last stopping test, bound on its relative error) per window of the last batch."""
+        r, e = np.zeros(cap), np.zeros(cap)
+        n = self._lib.swk_last_stopping_norms(self._h, _ptr(r), _ptr(e), cap)
+        if n < 0:
+            self._check(n)
+        return r[:min(n, cap)], e[:min(n, cap)]
 
     def set_norm_speculation(self, factor):
         self._check(self._lib.swk_set_norm_speculation(self._h, float(factor)))

@@ -120,8 +120,10 @@ struct PassCtx {
 };
 
 // The tile loop of one wave.  WS: this pass stores the sparse image; RU / WU: it reads / writes all of U (else frames 0..3).
+// umax: largest |U_{k-1}| / 128 this wave read in a pass near the stopping decision (WS: the sparse image is being stored) -- what the
+// error bound of the float32 / binary16 stopping norm needs (small_prologue, ialm_small_dev.h)
 template <int NK, int MODE, bool WS, bool RU, bool WU>
-__device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::NPAIR], float &zz, float &zz0)
+__device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::NPAIR], float &zz, float &zz0, float &umax)
 {
     using C = MCfg<NK>;
     constexpr int NB = C::NB, BP = C::BP, TP = C::TP;
@@ -208,6 +210,7 @@ __device__ __forceinline__ void pass_loop(const PassCtx &cx, d4 (&G)[MCfg<NK>::N
                         if (t == 0 || RU) {
                             const float zf = __builtin_fmaf(pkf, kUScale, -uf[t]);  // :293, in units of 128
                             if (t == 0) zz0 += zf * zf; else zz += zf * zf;
+                            if (WS) umax = fmaxf(umax, fabsf(uf[t]));
                         }
                     }
                 }
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
 #pragma unroll
     for (int i = 0; i < C::NPAIR; ++i) G[i] = d4{0.0, 0.0, 0.0, 0.0};
     float zz = 0.f, zz0 = 0.f;                   // sum of z^2 over frames >= 4 / frames 0..3 (float32: see the element-wise part)
+    float umax = 0.f;
 
     // a block owns groups of 8 consecutive tiles = 128 pixels (every 128-byte line of the u8 planes is touched by ONE
     // workgroup), two tiles per wave back to back; the valid tiles of a wave are a prefix of its sequence
@@ -331,17 +335,17 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
     // the per-window switches of this pass (sparse-image stores, all of U read / written) are wave-uniform but only
     // known on the device: one specialised copy of the tile loop per combination, chosen once
     const int flags = (ws ? 1 : 0) | (ru ? 2 : 0) | (wu ? 4 : 0);
-    if (MODE == 0) pass_loop<NK, 0, true, true, true>(cx, G, zz, zz0);
-    else if (MODE == 1) { if (wu) pass_loop<NK, 1, true, true, true>(cx, G, zz, zz0); else pass_loop<NK, 1, true, true, false>(cx, G, zz, zz0); }
+    if (MODE == 0) pass_loop<NK, 0, true, true, true>(cx, G, zz, zz0, umax);
+    else if (MODE == 1) { if (wu) pass_loop<NK, 1, true, true, true>(cx, G, zz, zz0, umax); else pass_loop<NK, 1, true, true, false>(cx, G, zz, zz0, umax); }
     else switch (flags) {
-        case 0: pass_loop<NK, 2, false, false, false>(cx, G, zz, zz0); break;
-        case 1: pass_loop<NK, 2, true, false, false>(cx, G, zz, zz0); break;
-        case 2: pass_loop<NK, 2, false, true, false>(cx, G, zz, zz0); break;
-        case 3: pass_loop<NK, 2, true, true, false>(cx, G, zz, zz0); break;
-        case 4: pass_loop<NK, 2, false, false, true>(cx, G, zz, zz0); break;
-        case 5: pass_loop<NK, 2, true, false, true>(cx, G, zz, zz0); break;
-        case 6: pass_loop<NK, 2, false, true, true>(cx, G, zz, zz0); break;
-        default: pass_loop<NK, 2, true, true, true>(cx, G, zz, zz0); break;
+        case 0: pass_loop<NK, 2, false, false, false>(cx, G, zz, zz0, umax); break;
+        case 1: pass_loop<NK, 2, true, false, false>(cx, G, zz, zz0, umax); break;
+        case 2: pass_loop<NK, 2, false, true, false>(cx, G, zz, zz0, umax); break;
+        case 3: pass_loop<NK, 2, true, true, false>(cx, G, zz, zz0, umax); break;
+        case 4: pass_loop<NK, 2, false, false, true>(cx, G, zz, zz0, umax); break;
+        case 5: pass_loop<NK, 2, true, false, true>(cx, G, zz, zz0, umax); break;
+        case 6: pass_loop<NK, 2, false, true, true>(cx, G, zz, zz0, umax); break;
+        default: pass_loop<NK, 2, true, true, true>(cx, G, zz, zz0, umax); break;
     }
 
     // ---- block-level, fixed-order combination of the four waves' Gram accumulators ----
@@ -377,9 +381,16 @@ __global__ __launch_bounds__(256, 2) void k_ialm_pass_m(IalmBuffers b, int sel, 
         __syncthreads();
         if (lane == 0) lds[NPAD * NPAD + wave] = zsum;
         __syncthreads();
-        if (tid == 0)
+        for (int off = 32; off; off >>= 1) umax = fmaxf(umax, __shfl_down(umax, off));
+        if (lane == 0) lds[NPAD * NPAD + 4 + wave] = (double)umax;
+        __syncthreads();
+        if (tid == 0) {
             b.zzpart[(int64_t)w * b.nblk + blockIdx.x] =
                 ((lds[NPAD * NPAD] + lds[NPAD * NPAD + 1]) + lds[NPAD * NPAD + 2]) + lds[NPAD * NPAD + 3];
+            // second half of the array: the block's largest |U_{k-1}| (0 in the passes that do not track it)
+            b.zzpart[(int64_t)(b.nwin + w) * b.nblk + blockIdx.x] =
+                fmax(fmax(lds[NPAD * NPAD + 4], lds[NPAD * NPAD + 5]), fmax(lds[NPAD * NPAD + 6], lds[NPAD * NPAD + 7])) * (double)kUUnscale;
+        }
     }
 }
 

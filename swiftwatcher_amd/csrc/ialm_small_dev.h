@@ -62,6 +62,19 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return total;
 }
 
+// Maximum over the workgroup; every thread gets it.  red: one double per wave.
+__device__ __forceinline__ double block_max(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int off = 32; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double m = 0.0;
+    for (int i = 0; i < nwaves; ++i) m = fmax(m, red[i]);
+    return m;
+}
+
 // Convergence test and scalar update.  Returns false when the window is (now) finished.
 __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int k, double lmbda, double tol, int maxiter,
                                                double *red, IalmScal &cur)
@@ -73,10 +86,38 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
     // further down, and all waves must take the same branches around the barriers that follow
     const bool full = st.ru != 0;
     const double dnorm = st.dnorm;
+    const double inv_mu_prev = st.cur.inv_mu;                    // 1 / mu_{k-1}: the scale of U_{k-1} = Y_{k-1} / mu_{k-1}
     if (k >= 1) {
         double acc = 0.0;
         for (int i = tid; i < nblk; i += nthreads) acc += b.zzpart[(int64_t)w * nblk + i];
         const double zz = block_sum(acc, red);
+        // M-state pass (b.guard > 0): how wrong can the stopping norm be?  z = P_k - U_{k-1} is formed in float32 from the binary16 copy
+        // of U_{k-1} (relative rounding eps_h = 2^-11; below 2^-14 x 128 absolute 2^-25 x 128) and summed in float32:
+        //   ||z^||^2 - ||z||^2 = -2 z.delta + ||delta||^2,   |delta_i| <= eps_h |U_i|
+        //   * ||delta||^2 <= eps_h^2 ||U_{k-1}||_F^2 = eps_h^2 n / mu_{k-1}^2 EXACTLY known: Y_{k-1} = polar(M_{k-1}) has n unit singular
+        //     values (image_filtering.py:290-294 with the always-full svp of :285), so ||Y||_F = sqrt(n);
+        //   * z.delta is a sum of independent bounded terms (the rounding errors): |z.delta| <= kappa eps_h max|U| ||z|| except with
+        //     probability 2 exp(-kappa^2 / 2) (Hoeffding; kappa = 8: 2.5e-14) -- max|U| is MEASURED by the passes near the decision.
+        //     (The deterministic bound ||delta|| / ||z|| <= eps_h sqrt(n) / (mu_{k-1} tol ||X||_F) is 1 % for a 64-frame window that stops
+        //     after 15 iterations: 300 x what is observed and no basis for a band)
+        //   * float32 accumulation: a lane adds nlane terms, relative error <= nlane 2^-24 in the worst case; lanes are added in float64.
+        // The band in which the comparison with tol is not trusted is the larger of the configured one and 4 x this bound.
+        double band = b.guard > 0.0 ? b.guard : 0.0;
+        if (band > 0.0 && full) {
+            double um = 0.0;
+            for (int i = tid; i < nblk; i += nthreads) um = fmax(um, b.zzpart[(int64_t)(b.nwin + w) * nblk + i]);
+            um = block_max(um, red);
+            const double T = tol * dnorm, eps_h = 4.8828125e-4;
+            const int ntiles = (b.P + 15) >> 4, groups = (ntiles + 7) >> 3;
+            const double nlane = 2.0 * (double)((groups + nblk - 1) / nblk) * (double)((b.n + 3) >> 2);
+            double e = 0.5 * (nlane + 2.0) * 5.9604644775390625e-8;
+            if (k >= 2) {
+                const double rho = eps_h * sqrt((double)b.n) * inv_mu_prev / T;
+                e += 8.0 * eps_h * um / T + 0.5 * rho * rho + sqrt((double)b.P * (double)b.n) * 3.814697265625e-6 / T;
+            }
+            if (tid == 0) st.norm_err = e;
+            band = fmax(band, 4.0 * e);
+        }
         // a pass that read all of U_{k-1} delivers ||Z_k||^2; one that read only frames 0..3 of it (IalmWin::ru == 0)
         // delivers the sum over those frames: a LOWER bound
         const double ratio = sqrt(zz) / dnorm;                   // :297
@@ -89,7 +130,6 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         }
         // M-state pass: the norm is a float32 sum over a binary16 copy of Y/mu (relative error about 1e-6).  Inside the guard
         // band the comparison with tol is not trusted: the window stops here and the host runs it again with the float64 norm.
-        const double band = b.guard > 0.0 ? b.guard : 0.0;
         if (full && band > 0.0 && k < maxiter && fabs(ratio / tol - 1.0) < band) {
             if (tid == 0) { st.iter = k; st.done = 1; st.redo |= 4; atomicSub(b.active, 1); }
             return false;
@@ -100,6 +140,7 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
             if (tid == 0) { st.iter = k; st.done = 1; st.redo |= 2; atomicSub(b.active, 1); }
             return false;
         }
+        if (tid == 0 && full) st.last_ratio = ratio;
         if ((full && ratio < tol) || k >= maxiter) {
             // the answer's sparse image is the one pass k-1 wrote (ialm_mfma.hip, M-state pass): if that pass ran
             // with its stores switched off, the speculation below failed and the host runs the batch again

@@ -62,6 +62,7 @@ struct swk_ctx {
     int sparse_backoff = 0, norm_backoff = 0;   // batches for which a guess stays off after it failed (same video, same behaviour)
     int eig_method = 0;                  // 0 Newton-Schulz (MFMA), 1 Jacobi
     hipEvent_t ev_poll[2] = {nullptr, nullptr};   // the host polls convergence two iterations late (run_ialm)
+    std::vector<IalmWin> last_hw;        // host copy of the last batch's per-window IALM state (gather_iters): diagnostics
     IalmWin *last_win = nullptr;         // per-window IALM state of the last run
     int last_nwin = 0;
     int64_t pstride = 0;                 // plane pitch of the A/Y/E workspaces of the last IALM run
@@ -262,7 +263,7 @@ int run_ialm(swk_ctx *ctx, const uint8_t *dX, int nwin, int n, int P, double lmb
     NEED(ctx, SL_BM, (size_t)nwin * n * n * 8, b.Bm);
     NEED(ctx, SL_VPREV, (size_t)nwin * n * n * 8, b.Vprev);
     NEED(ctx, SL_GPART, (size_t)nwin * b.nblk * n * n * 8, b.gpart);
-    NEED(ctx, SL_ZZPART, (size_t)nwin * b.nblk * 8, b.zzpart);
+    NEED(ctx, SL_ZZPART, (size_t)2 * nwin * b.nblk * 8, b.zzpart);          // [nwin][nblk] sums of z^2, then [nwin][nblk] max |U| (M-state pass)
     NEED(ctx, SL_WIN, (size_t)nwin * sizeof(IalmWin), b.win);
     NEED(ctx, SL_ACTIVE, 16 * sizeof(int), b.active);
     double *wide_work = nullptr;
@@ -405,6 +406,7 @@ int gather_iters(swk_ctx *ctx, int32_t *h_iters, int32_t *d_iters)
     HIPCHK(ctx, hipMemcpyAsync(hw.data(), ctx->last_win, (size_t)nwin * sizeof(IalmWin), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int32_t> it(nwin);
+    ctx->last_hw = hw;
     ctx->last_int_start = 0;
     ctx->last_eig_sweeps = 0;
     for (int w = 0; w < nwin; ++w) {
@@ -698,6 +700,17 @@ int32_t swk_prof_refined_windows(swk_ctx *ctx, int64_t *refined, int64_t *unrefi
     if (refined) *refined = ctx->refined_windows;
     if (unrefined) *unrefined = ctx->unrefined_windows;
     return SWK_OK;
+}
+
+int32_t swk_last_stopping_norms(swk_ctx *ctx, double *ratio, double *err_bound, int32_t cap)
+{
+    if (!ctx || cap < 0) return SWK_ERR_ARG;
+    const int n = (int)ctx->last_hw.size();
+    for (int w = 0; w < n && w < cap; ++w) {
+        if (ratio) ratio[w] = ctx->last_hw[w].last_ratio;
+        if (err_bound) err_bound[w] = ctx->last_hw[w].norm_err;
+    }
+    return n;
 }
 
 int32_t swk_prof_redo_windows(swk_ctx *ctx, int64_t *windows)

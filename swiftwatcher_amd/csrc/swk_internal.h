@@ -75,6 +75,7 @@ struct IalmWin {
     int int_gram;                  // the Gram matrix of the first iteration came from k_gram_u8 (unscaled X^T X)
     unsigned long long pass_b16;   // algorithmic bytes per element moved by the passes 1..iter of this window, in 1/16 B
     double zf2;                    // ||(G/s)^(-1/2)||_F^2 of the last Newton-Schulz solve (0: none yet): where the next solve's bound starts
+    double norm_err;               // M-state pass: bound on the relative error of the float32 / binary16 stopping norm at the last test
     double cond_sum;               // ||G_1||_F sum_i 1 / lambda_i(G_1) of the first solve (>= cond(G_1)): the ill-conditioning estimate
     int refine;                    // accurate first iteration (ialm_refine.hip): 0 not needed, 1 asked for by k_ialm_small (k = 0),
                                    // 2 done, 3 given up (rank deficient: the standard route's defined result stands),
@@ -92,7 +93,7 @@ struct IalmBuffers {
     double *Bm;                    // [nwin][n][n]   I - W/mu
     double *Vprev;                 // [nwin][n][n]   eigenvectors of the previous solve (warm start)
     double *gpart;                 // [nwin][nblk][n][n]
-    double *zzpart;                // [nwin][nblk]
+    double *zzpart;                // [nwin][nblk] partial sums of z^2; the M-state pass appends [nwin][nblk] largest |U_{k-1}| per block
     IalmWin *win;                  // [nwin]
     int *active;                   // device counter of windows not yet converged
     int nwin, n, P, nblk;

@@ -48,5 +48,7 @@ def test_pass_keeps_its_registers_and_its_loads_in_flight(pass_asm, nk, mode, co
     assert count(r"v_mfma_f64_16x16x4") == copies * (nk * nb + 2 * nb * (nb + 1))
     # a tile's loads are issued together: at most two full waits per copy of the loop (tile end, prologue / epilogue)
     # (the first-iteration pass, 1 launch in 16, also waits for its table of X / dual_norm)
-    assert count(r"vmcnt\(0\)") <= (2 * copies if mode == 2 else 8), "the compiler serialised the tile's loads"
+    # (+ 4 since round 4: the joins behind the loop copies that carry the largest |U| read -- the stopping norm's error bound -- out of
+    #  the loop wait once each, after the loop)
+    assert count(r"vmcnt\(0\)") <= (2 * copies + 4 if mode == 2 else 8), "the compiler serialised the tile's loads"
     assert count(r"buffer_load") >= copies * nk            # M of every k-step at least, per copy
