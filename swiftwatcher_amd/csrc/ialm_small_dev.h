@@ -103,7 +103,7 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
         //   * float32 accumulation: a lane adds nlane terms, relative error <= nlane 2^-24 in the worst case; lanes are added in float64.
         // The band in which the comparison with tol is not trusted is the larger of the configured one and 4 x this bound.
         double band = b.guard > 0.0 ? b.guard : 0.0;
-        if (band > 0.0 && full) {
+        if (b.U != nullptr && full) {          // the M-state pass (the bound is kept as a diagnostic also when the band is switched off)
             double um = 0.0;
             for (int i = tid; i < nblk; i += nthreads) um = fmax(um, b.zzpart[(int64_t)(b.nwin + w) * nblk + i]);
             um = block_max(um, red);
@@ -116,7 +116,7 @@ __device__ __forceinline__ bool small_prologue(const IalmBuffers &b, int w, int 
                 e += 8.0 * eps_h * um / T + 0.5 * rho * rho + sqrt((double)b.P * (double)b.n) * 3.814697265625e-6 / T;
             }
             if (tid == 0) st.norm_err = e;
-            band = fmax(band, 4.0 * e);
+            if (band > 0.0) band = fmax(band, 4.0 * e);
         }
         // a pass that read all of U_{k-1} delivers ||Z_k||^2; one that read only frames 0..3 of it (IalmWin::ru == 0)
         // delivers the sum over those frames: a LOWER bound
