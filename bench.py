@@ -88,6 +88,9 @@ def parse():
                     help="21-frame windows at the head of the count_loop clip that also go through the CPU restatement's pipeline (count_oracle)")
     ap.add_argument("--video-windows", type=int, default=24, help="21-frame windows per video of the video_sharded leg (0 = skip the leg)")
     ap.add_argument("--videos-per-gpu", type=int, default=1)
+    ap.add_argument("--video-config", default="auto", choices=["auto", "4", "5"],
+                    help="video_sharded: BASELINE config 4 (1080p frames in host memory) or 5 (4K videos as ROI stream files); auto = 4 up to "
+                         "four ranks, 5 beyond")
     ap.add_argument("--verify-all-videos", action="store_true", help="video_sharded: rank 0 recounts every video (default: the first and the last)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher rehearsal without any GPU work: the ranks join the process group (SWK_DIST_BACKEND, gloo on CPU-only "
@@ -437,7 +440,7 @@ def video_sharded_leg(args, rank, world, local, clf):
     from swiftwatcher_amd import image_filtering as img
     from swiftwatcher_amd.io_frames import ArrayReader, PresegmentingReader
     from swiftwatcher_amd.io_roi_stream import RoiFrame, RoiStreamReader, RoiStreamWriter, margin_rect
-    big = world > 4
+    big = world > 4 if args.video_config == "auto" else args.video_config == "5"
     n, nf = 21, 21 * args.video_windows
     if big:
         geo, frame_hw, corners = synthetic.P3, (2160, 3840), [(1580, 1240), (2260, 1244)]          # a 680-px chimney of a 4K frame
