@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_refine_start(IalmBuffers
     } else {
         // ---- the window's first shrinkage clips (it did not start on the integer cores): K = M_1^T M_1 accumulated in double-double
         //      from the pixels.  M_1 takes one of 256 values (the start pass's expressions, image_filtering.py:272, 282-284, on the 8-bit
-        //      value); 64 pixels at a time are tabulated into LDS, a thread owns the pairs (i >= j) tid, tid + 1024, ... ----
+        //      value); 16 NB pixels at a time are tabulated into LDS, a thread owns the pairs (i >= j) tid, tid + 1024, ... ----
         const double dual = st.dual_norm, thr = st.cur.thr;
         const uint8_t *X = b.X + (int64_t)w * n * b.P;
         const int npairs = n * (n + 1) / 2;
@@ -137,10 +137,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_refine_start(IalmBuffers
             pi[q] = pr < npairs ? i : -1;
             pj[q] = pr - i * (i + 1) / 2;
         }
-        for (int p0 = 0; p0 < b.P; p0 += 64) {
+        // (CH pixels at a time: a row of the staging tile holds PITCH = 16 NB + 2 values)
+        constexpr int CH = NPAD;
+        for (int p0 = 0; p0 < b.P; p0 += CH) {
             __syncthreads();
-            for (int idx = tid; idx < n * 64; idx += nthreads) {
-                const int f = idx >> 6, p = p0 + (idx & 63);
+            for (int idx = tid; idx < n * CH; idx += nthreads) {
+                const int f = idx / CH, p = p0 + (idx - f * CH);
                 double m = 0.0;
                 if (p < b.P) {
                     const double x = (double)X[(int64_t)f * b.P + p];
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_refine_start(IalmBuffers
                     const double e = fmax(raw - thr, 0.0) + fmin(raw + thr, 0.0);   // :283
                     m = (x - e) + inv_mu * y;                               // :284
                 }
-                T[f * PITCH + (idx & 63)] = m;
+                T[f * PITCH + (idx - f * CH)] = m;
             }
             __syncthreads();
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_ialm_refine_start(IalmBuffers
                 if (pi[q] < 0) continue;
                 const double *ri = T + pi[q] * PITCH, *rj = T + pj[q] * PITCH;
                 dd a = acc[q];
-                for (int p = 0; p < 64; ++p) a = dd_add(a, two_prod(ri[p], rj[p]));
+                for (int p = 0; p < CH; ++p) a = dd_add(a, two_prod(ri[p], rj[p]));
                 acc[q] = a;
             }
         }

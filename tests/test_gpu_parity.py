@@ -238,6 +238,22 @@ def test_accurate_first_iteration_of_ill_conditioned_windows(golden_dir):
                 assert c.refined_windows == after
                 worst_off = max(worst_off, np.abs(A0[rows] - g["A_rows"]).max(), np.abs(E0[rows] - g["E_rows"]).max())
     assert worst_off > 1e-5
+    # the refinement forced (tau = 1e-12) on well-conditioned fixtures of 7, 21 and 64 frames, from the integer start and -- integer start
+    # off, or a window whose first shrinkage clips (47x94x21) -- from the double-double Gram matrix of the pixels: every staging-tile
+    # width of the kernel (16, 32, 64 pixels per chunk); results stay the reference's
+    c.set_start_refine(1e-12)
+    for name in ("ialm_128x160x7", "ialm_64x96x21", "ialm_47x94x21", "ialm_64x96x64"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        frames = g["frames"]
+        n, H, W = frames.shape
+        for int_start in (1, 0):
+            c.set_integer_start(int_start)
+            before = c.refined_windows
+            A, E, iters = c.ialm(frames.reshape(n, H * W))
+            assert c.refined_windows[0] - before[0] == 1, (name, int_start)
+            assert iters == int(g["iters"]), (name, int_start)
+            assert np.abs(A[g["rows"]] - g["A_rows"]).max() < 1e-6 and np.abs(E[g["rows"]] - g["E_rows"]).max() < 1e-6, (name, int_start)
+    c.set_integer_start(1)
     # a window of the 21-frame CLI queue at config 1's size is well enough conditioned: not touched
     g = np.load(os.path.join(golden_dir, "ialm_47x94x21.npz"))
     c.set_start_refine(1e-5)
