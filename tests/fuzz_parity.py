@@ -94,11 +94,17 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     first = seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     ctx = _lib.Context(0)
+    # round 4: every fourth seed runs on a context without the integer start and with the accurate first iteration FORCED -- the
+    # float64 start pass and the double-double Gram matrix from the pixels (csrc/ialm_refine.hip) get the same random windows
+    # (tools/spec_soak.py found a bug there that no fixed test had: staging tiles narrower than 64 pixels)
+    alt = _lib.Context(0)
+    alt.set_integer_start(0)
+    alt.set_start_refine(1e-12)
     t0 = time.time()
     done = bad = 0
     by_kind = {}
     while time.time() - t0 < budget:
-        cfg, problems = check(ctx, seed)
+        cfg, problems = check(alt if seed % 4 == 3 else ctx, seed)
         done += 1
         by_kind[cfg["kind"]] = by_kind.get(cfg["kind"], 0) + 1
         if problems:
@@ -107,7 +113,8 @@ def main():
         if done % 20 == 0:
             print("... %d windows, %d mismatches, %.0f s" % (done, bad, time.time() - t0), flush=True)
         seed += 1
-    print(json.dumps({"windows": done, "mismatches": bad, "by_kind": by_kind, "guard_windows": ctx.guard_windows, "redo_batches": ctx.redo_batches,
+    print(json.dumps({"windows": done, "mismatches": bad, "by_kind": by_kind, "guard_windows": ctx.guard_windows + alt.guard_windows, "redo_batches": ctx.redo_batches + alt.redo_batches,
+                      "redo_windows": ctx.redo_windows + alt.redo_windows, "refined_windows": [ctx.refined_windows, alt.refined_windows],
                       "first_seed": first, "seconds": round(time.time() - t0, 1)}))
     return 1 if bad else 0
 

@@ -16,3 +16,15 @@ def test_random_windows_match_the_oracle():
         assert not problems, "seed %d %r: %s" % (seed, cfg, "; ".join(problems))
     assert len(kinds) >= 5
     ctx.close()
+    # the same random windows' second half on a context without the integer start and with the accurate first iteration forced:
+    # the float64 start pass and the double-double Gram matrix from the pixels (every staging-tile width occurs among the seeds)
+    alt = _lib.Context(0)
+    alt.set_integer_start(0)
+    alt.set_start_refine(1e-12)
+    frames_seen = set()
+    for seed in range(100012, 100024):
+        cfg, problems = fuzz_parity.check(alt, seed)
+        frames_seen.add((cfg["n"] + 15) // 16)
+        assert not problems, "seed %d %r (f64 start, refinement forced): %s" % (seed, cfg, "; ".join(problems))
+    assert alt.refined_windows[0] >= 6 and len(frames_seen) >= 3
+    alt.close()
