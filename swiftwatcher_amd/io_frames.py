@@ -94,6 +94,11 @@ class PresegmentingReader:
         self._exhausted = False
         self._sync_counters()
 
+    def set_classifier(self, classifier):
+        """Score every batch for this classifier as soon as it is segmented (the reference builds its classifier after the reader)."""
+        import weakref
+        self._classifier_hint = weakref.ref(classifier) if classifier is not None else None
+
     # the wrapped reader runs ahead: the counters the caller sees are those of the windows handed out
     def _sync_counters(self, snap=None):
         r = self.reader
