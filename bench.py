@@ -166,6 +166,10 @@ def rehearse(args):
     """--rehearse-launch: everything of the multi-rank protocol except the GPU work (CPU test of the launcher; gloo)."""
     import torch.distributed as dist
     from swiftwatcher_amd import distributed as swd
+    if os.environ.get("SWK_REHEARSE_FAIL_RANK") == os.environ.get("RANK", "0"):
+        # (test hook of the launcher: this rank dies before it joins the process group, the others would wait for it for ever)
+        sys.stderr.write("rehearsal: rank %s fails on purpose\n" % os.environ.get("RANK", "0"))
+        sys.exit(3)
     rank, world, local = swd.init(os.environ.get("SWK_DIST_BACKEND", "gloo"))
     swd.barrier()
     t0 = time.perf_counter()

@@ -124,6 +124,25 @@ def test_bench_launches_its_own_ranks():
     assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["frames"] == 4 * 64 * 2 for r in line["per_rank"])
 
 
+def test_bench_launcher_ends_the_other_ranks_when_one_dies():
+    """A rank that dies before it joins the process group would leave the others in init for ever: the launcher watches
+    every child, ends the rest, returns non-zero and keeps each rank's stderr tail."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWK_DIST_BACKEND="gloo", SWK_REHEARSE_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch", "--steps", "1", "--windows", "2"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120                                   # not the process group's own timeout (minutes)
+    assert "rank 1 exited with code 3" in out.stderr and "fails on purpose" in out.stderr, out.stderr[-1500:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 _VIDEO_RANK = r"""
 import json, os, sys
 sys.path.insert(0, {root!r})
