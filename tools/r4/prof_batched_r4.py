@@ -18,6 +18,9 @@ roi_mask = np.zeros((212, 424), np.uint8); roi_mask[100:, 42:382] = 255
 q = ds.FrameQueue(); q.push_list_of_frames(frames[:n], list(range(n)), ["t"] * n); q.preprocess_queue(crop_region, None); q.segment_queue((24, 24), crop_region)
 crops = [s.segment_image for f in q for s in f.segments]
 sd = cref.calibrate_head(cref.random_state_dict(4), crops[:60])
+if "pt" in sys.argv:
+    g = np.load(os.path.join(ROOT, "tests", "golden", "classifier_model_pt.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
 clf = SegmentClassifier.from_state_dict(sd, batch_size=8192)
 log = []
 def wrap(obj, name, tag):
