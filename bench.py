@@ -380,13 +380,22 @@ def reference_call_pattern(ctx_device, clf, args, geo, clf_state=None):
             traceback.print_exc()
             return {"error": repr(exc)}
 
+    def play(reader, classifier, **kw):
+        try:
+            return pipeline.swift_counting_algorithm(reader, crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
+        finally:
+            if hasattr(reader, "close"):          # a reader that segments ahead: the batch in flight, the frames its prepared windows hold
+                reader.close()
+
     def run_loop_(make_reader, classifier, **kw):
-        events = pipeline.swift_counting_algorithm(make_reader(1), crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
+        events = play(make_reader(1), classifier, **kw)
         del events
         gc.collect()
+        reader = make_reader(cycles)
         t0 = time.perf_counter()
-        events = pipeline.swift_counting_algorithm(make_reader(cycles), crop_region, roi_mask, queue_size=n, classifier=classifier, keep_stages=True, **kw)
+        events = play(reader, classifier, **kw)
         dt = time.perf_counter() - t0
+        del reader
         return {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_window": round(dt / (args.loop_windows * cycles) * 1e3, 3),
                 "frames": total, "events": len(events), "count": int(ec.count_swifts(events))}
 
@@ -479,19 +488,20 @@ def video_sharded_leg(args, rank, world, local, clf):
 
     def count_video(reader):
         pre = PresegmentingReader(reader, crop_region, queue_size=n, windows=8, device=local)
-        events = pipeline.swift_counting_algorithm(pre, crop_region, roi_mask, queue_size=n, classifier=clf, device=local)
+        try:
+            events = pipeline.swift_counting_algorithm(pre, crop_region, roi_mask, queue_size=n, classifier=clf, device=local)
+        finally:
+            pre.close()          # the batch it was still segmenting ahead, and the frames its prepared windows hold
         count = int(ec.count_swifts(events))
         return (count, len(events) - count, nf)
 
     def rewind(reader):
-        if isinstance(reader, RoiStreamReader):
-            path = reader.filepath
-            reader.close()
-            return RoiStreamReader(path, device=local)
+        if isinstance(reader, RoiStreamReader):          # (closed by the presegmenting reader's close())
+            return RoiStreamReader(reader.filepath, device=local)
         return ArrayReader(reader.frames)
 
     mine = swd.shard(videos, rank, world)
-    failed, local_counts, dt, plays = 0, {}, 0.0, []
+    failed, local_counts, dt, plays, readers = 0, {}, 0.0, [], {}
     try:
         readers = {i: make_reader(i) for i in mine}
         for i in mine:                                   # untimed first play: allocations, HIP graphs of the window sizes, page faults
@@ -541,7 +551,10 @@ def video_sharded_leg(args, rank, world, local, clf):
                 same = same and tuple(int(v) for v in table[i].tolist()) == count_video(make_reader(i))
             out["counts_equal_single_rank"] = bool(same)
             out["verified_videos"] = check
+    del readers
     tmp.cleanup()
+    import gc
+    gc.collect()          # 3 GB of frames per video go back before the host-side sub-results are timed
     return out
 
 
