@@ -764,7 +764,9 @@ def main():
     redo = ctx.redo_batches - redo0
 
     # ---- configs 4 / 5 as worded: videos sharded over the ranks, per-video counts gathered (every rank takes part) ----
-    video_sharded = video_sharded_leg(args, rank, world, local, clf) if args.video_windows > 0 else None
+    # (with one rank the leg runs last, below: its gigabytes of host frames would otherwise leave the Python heap in a state that
+    #  costs the host-side sub-results -- drop_in, count_loop -- up to half of their throughput in this sandbox)
+    video_sharded = video_sharded_leg(args, rank, world, local, clf) if args.video_windows > 0 and world > 1 else None
 
     # ---- per-rank counts gathered over RCCL (the only collective of the path) ----
     it_host = iters.cpu().numpy()
@@ -921,6 +923,13 @@ def main():
                 import traceback
                 traceback.print_exc()
                 res["cpu_baseline"] = {"error": repr(exc)}
+        if world == 1 and args.video_windows > 0:
+            try:
+                res["video_sharded"] = video_sharded_leg(args, rank, world, local, clf)
+            except Exception as exc:          # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                res["video_sharded"] = {"error": repr(exc)}
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
