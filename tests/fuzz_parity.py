@@ -4,7 +4,7 @@ blocks), duplicated last frames and null padding -- per window the iteration cou
 region records equal.  Windows hold >= 1.4e5 elements (below about 1.1e5 the reference itself is LAPACK-dependent)
 and <= 1.2e6 (the oracle's SVDs).  Prints one line per mismatch with the seed that reproduces it, and a summary.
 
-    python3 tests/fuzz_parity.py [seconds] [first seed]          (tests/test_fuzz_parity.py runs a fixed dozen of seeds)"""
+    python3 tests/fuzz_parity.py [seconds] [first seed] [--rotate]          (tests/test_fuzz_parity.py runs a fixed dozen of seeds)"""
 import json
 import os
 import sys
@@ -91,8 +91,9 @@ def check(ctx, seed):
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    first = seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if len(args) > 0 else 300.0
+    first = seed = int(args[1]) if len(args) > 1 else 100000
     ctx = _lib.Context(0)
     # round 4: every fourth seed runs on a context without the integer start and with the accurate first iteration FORCED -- the
     # float64 start pass and the double-double Gram matrix from the pixels (csrc/ialm_refine.hip) get the same random windows
@@ -100,11 +101,23 @@ def main():
     alt = _lib.Context(0)
     alt.set_integer_start(0)
     alt.set_start_refine(1e-12)
+    # "--rotate": two more contexts take turns -- the Jacobi solver under the A/Y-state pass, and guesses that fail on purpose (the
+    # stores of the sparse image start late, the stopping norm is formed every other iteration to the end, a guard band of 5 %): the
+    # per-window rerun paths of run_ialm (nested calls, gathered windows) get random windows and random batch sizes
+    rotate = "--rotate" in sys.argv
+    jac = _lib.Context(0)
+    jac.set_eig_method(1)
+    jac.set_ialm_variant(2)
+    redo = _lib.Context(0)
+    redo.set_sparse_speculation(2.0)
+    redo.set_norm_speculation(1e-9)
+    redo.set_norm_guard(0.05)
+    pool = [ctx, jac, redo, alt] if rotate else [ctx, ctx, ctx, alt]
     t0 = time.time()
     done = bad = 0
     by_kind = {}
     while time.time() - t0 < budget:
-        cfg, problems = check(alt if seed % 4 == 3 else ctx, seed)
+        cfg, problems = check(pool[seed % 4], seed)
         done += 1
         by_kind[cfg["kind"]] = by_kind.get(cfg["kind"], 0) + 1
         if problems:
@@ -115,6 +128,7 @@ def main():
         seed += 1
     print(json.dumps({"windows": done, "mismatches": bad, "by_kind": by_kind, "guard_windows": ctx.guard_windows + alt.guard_windows, "redo_batches": ctx.redo_batches + alt.redo_batches,
                       "redo_windows": ctx.redo_windows + alt.redo_windows, "refined_windows": [ctx.refined_windows, alt.refined_windows],
+                      "rotate": rotate, "rerun_context": {"redo_batches": redo.redo_batches, "redo_windows": redo.redo_windows, "guard_windows": redo.guard_windows},
                       "first_seed": first, "seconds": round(time.time() - t0, 1)}))
     return 1 if bad else 0
 
