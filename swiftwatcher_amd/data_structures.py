@@ -408,12 +408,14 @@ def stack_frames(frames, crop_region, min_seg_size, buffer):
         h, w = first.roi.shape[:2]
         if ya < oy or xa < ox or yb > oy + h or xb > ox + w:
             raise ValueError("the ROI stream does not hold the crop region plus its margin")
-        block = first.block
-        last = len(frames) - 1
-        if block is not None and block.shape[0] == len(frames) and all(f.block is block and f.slot == last - i for i, f in enumerate(frames)):
-            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), True          # the block lies in file order: read it backwards
-        if block is not None and block.shape[0] == len(frames) and all(f.block is block and f.slot == i for i, f in enumerate(frames)):
-            return block, (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), False
+        block, s0, last = first.block, first.slot, len(frames) - 1
+        # (one snapshot per frame: the reader's thread may give a frame private pixels meanwhile -- then it no longer matches and the
+        #  copy below is taken)
+        where = [(f.block, f.slot) for f in frames]
+        if block is not None and s0 - last >= 0 and all(b is block and sl == s0 - i for i, (b, sl) in enumerate(where)):
+            return block[s0 - last:s0 + 1], (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), True          # the piece lies in file order: read it backwards
+        if block is not None and all(b is block and sl == s0 + i for i, (b, sl) in enumerate(where)):
+            return block[s0:s0 + last + 1], (x0 - ox, y0 - oy), (y1 - y0, x1 - x0), False
         stack = buffer((len(frames), yb - ya, xb - xa) + first.shape[2:])
         _lib.stage_frames([f.roi for f in frames], ya - oy, yb - oy, xa - ox, xb - ox, stack)
         return stack, (x0 - xa, y0 - ya), (y1 - y0, x1 - x0), False
@@ -444,11 +446,22 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
         return []
     n = len(windows[0][0])
     ctx = _lib.default_context(device)
-    ordered = []
     for frames, _, _ in windows:
         if len(frames) != n:
             raise ValueError("every window needs the same number of frames")
-        ordered.extend(frames[::-1])                         # queue index 0 = newest = last frame read (:134)
+    # windows of a ROI-stream reader that lie side by side in one of its page-locked blocks (it places the windows it reads ahead
+    # that way): taken in REVERSE order the batch is that piece of the block read backwards -- every window newest frame first --
+    # and goes to the library as it lies; windows are independent, only the bookkeeping below has to know the order
+    W = len(windows)
+    order = list(range(W))
+    if W > 1 and all(getattr(w[0][0], "block", None) is not None for w in windows):
+        blk, at = windows[0][0][0].block, windows[0][0][0].slot
+        if all(fr.block is blk and fr.slot == at + i for i, fr in enumerate(f for w in windows for f in w[0])):
+            order.reverse()
+    pos = {w: i for i, w in enumerate(order)}                # window w is the pos[w]-th of the batch
+    ordered = []
+    for w in order:
+        ordered.extend(windows[w][0][::-1])                  # queue index 0 = newest = last frame read (:134)
     stack, (rx, ry), (Hc, Wc), backwards = stack_frames(ordered, crop_region, min_seg_size, ctx.staging)
     res = ctx.batch_run(stack, len(windows), n, crop=(rx, ry, Wc, Hc), params=params, stages=(), reverse_frames=backwards)
     nseg = res["nseg"]
@@ -458,13 +471,13 @@ def segment_windows(windows, crop_region, min_seg_size=(24, 24), device=0, param
     if batch is not None and classifier is not None:
         batch.launch(classifier)
     if info is not None:
-        info["iters"] = [int(v) for v in res["iters"]]
-    slots = [None] * (len(windows) * n)
+        info["iters"] = [int(res["iters"][pos[w]]) for w in range(W)]
+    slots = [None] * (W * n)
     out = []
     for w, (frames, numbers, stamps) in enumerate(windows):
         popped = [Frame(frames[k], numbers[k], stamps[k]) for k in range(n)]          # oldest first
         for k, fr in enumerate(popped):
-            slots[w * n + (n - 1 - k)] = fr
+            slots[pos[w] * n + (n - 1 - k)] = fr
         out.append(popped)
     window_segments(res["segs"], nseg, slots, tuple(min_seg_size), crop_region, batch)
     return out

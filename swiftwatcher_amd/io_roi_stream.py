@@ -157,7 +157,8 @@ def write_roi_stream(path, frames, crop_region, fps=30.0, min_seg_size=(24, 24))
 class RoiStreamReader:
     """FrameReader over a ROI stream file (io_video.py:13-82 bookkeeping).  prefetch=True reads the next window ahead in a thread."""
 
-    BLOCKS = 6          # a block is reused five windows later: by then few of its frames are still referenced (tracks last 1-2 windows)
+    BLOCKS = 6          # one window per block (ahead = 1): a block is reused five windows later, by then few of its frames are still
+                        # referenced (tracks last 1-2 windows); blocks of `ahead` windows: a ring of three or more
     MAX_BLOCKS = 32     # the ring grows when most frames of the block in turn are still in use (a caller that reads many windows ahead)
 
     def __init__(self, path, start=0, end=0, prefetch=True, device=0, ahead=1):
@@ -194,7 +195,7 @@ class RoiStreamReader:
         self.read_errors = 0
         self.device = device
         self._midnight = datetime.datetime.combine(datetime.date.today(), datetime.time())
-        self._blocks, self._alive, self._turn = [], [], 0
+        self._blocks, self._alive, self._turn, self._used = [], [], 0, 0
         self._spare = []                     # pixel buffers of detached frames that have died since
         self._prefetch = prefetch
         self.ahead = max(int(ahead), 1)      # windows read ahead of the caller (a caller that takes several windows per GPU call sets it)
@@ -256,23 +257,34 @@ class RoiStreamReader:
 
     # ---- a window at a time: one page-locked block in queue order, next window read ahead ----
     def _block(self, n):
-        """The page-locked block the next window goes into (the ring's next one; frames that still live in it get private pixels)."""
-        if not self._blocks or self._blocks[0].shape[0] != n:
-            self._blocks = [_lib.pinned_empty((n,) + self.roi_shape, np.uint8, device=self.device) for _ in range(self.BLOCKS)]
-            self._alive = [[] for _ in range(self.BLOCKS)]
-            self._turn = 0
-        b = self._turn
+        """Where the next window goes: (page-locked block, first slot, its list of live frames).  A block holds `ahead` consecutive
+        windows side by side (a caller that takes several windows per GPU call -- the reader that segments ahead, windows_per_call --
+        then hands the library ONE contiguous piece of it: no staging copy for a batch either); windows are placed in the order they
+        are asked for.  The ring's next block is taken when the current one is full; frames that still live in a block about to be
+        reused get private pixels first."""
+        group = max(int(self.ahead), 1)
+        if not self._blocks or self._blocks[0].shape[0] != group * n:
+            ring = self.BLOCKS if group == 1 else max(3, -(-self.BLOCKS // group) + 2)
+            self._blocks = [_lib.pinned_empty((group * n,) + self.roi_shape, np.uint8, device=self.device) for _ in range(ring)]
+            self._alive = [[] for _ in range(ring)]
+            self._turn, self._used = 0, group          # (the first call below moves on to block 0)
+            self._turn = len(self._blocks) - 1
+        if self._used < group:
+            base = self._used * n
+            self._used += 1
+            return self._blocks[self._turn], base, self._alive[self._turn]
+        b = (self._turn + 1) % len(self._blocks)
         live = [fr for fr in (ref() for ref in self._alive[b]) if fr is not None and fr.block is self._blocks[b]]
-        if len(live) > n // 2 and len(self._blocks) < self.MAX_BLOCKS:
-            # most of that window is still in use (its frames wait to be segmented, or sit in long tracks): a new block instead
-            self._blocks.insert(b, _lib.pinned_empty((n,) + self.roi_shape, np.uint8, device=self.device))
+        if len(live) > (group * n) // 2 and len(self._blocks) < self.MAX_BLOCKS:
+            # most of that block is still in use (its frames wait to be segmented, or sit in long tracks): a new block instead
+            self._blocks.insert(b, _lib.pinned_empty((group * n,) + self.roi_shape, np.uint8, device=self.device))
             self._alive.insert(b, [])
         else:
             for fr in live:
                 fr.detach(self._spare)
             self._alive[b] = []
-        self._turn = (b + 1) % len(self._blocks)
-        return self._blocks[b], self._alive[b]
+        self._turn, self._used = b, 1
+        return self._blocks[b], 0, self._alive[b]
 
     def _fill(self, block, first, n):
         """Pixels of frames first .. first + n - 1 into the block, frame k at slot k (the order of the file: ONE read for the window's
@@ -320,11 +332,11 @@ class RoiStreamReader:
                 import queue
                 self._jobs = queue.Queue()
                 threading.Thread(target=self._reader_loop, args=(self._jobs,), daemon=True).start()
-            block, alive = self._block(n)
+            block, base, alive = self._block(n)
             done = threading.Event()
             done.error = None
-            self._jobs.put((block, first, n, done))
-            self._pending.append((first, n, (block, alive), done))
+            self._jobs.put((block[base:base + n], first, n, done))
+            self._pending.append((first, n, (block, base, alive), done))
             first += n
 
     def _wait(self, pend):
@@ -337,20 +349,20 @@ class RoiStreamReader:
         if self._pending and self._pending[0][0] == first and self._pending[0][1] == n:
             pend = self._pending.pop(0)
             self._wait(pend)
-            block, alive = pend[2]
+            block, base, alive = pend[2]
         else:
             for pend in self._pending:           # read ahead for another position or window size: let it finish, then read here
                 self._wait(pend)
             self._pending = []
-            block, alive = self._block(n)
-            self._fill(block, first, n)
+            block, base, alive = self._block(n)
+            self._fill(block[base:base + n], first, n)
         frames, numbers, stamps = [], [], []
         for k in range(n):
             number = self.next_frame_number
             if not self.start_frame <= number <= self.end_frame:
-                fr, num, ts = RoiFrame(block[k], self.origin, self.full_shape, block, k), -1, "00:00:00.000"
+                fr, num, ts = RoiFrame(block[base + k], self.origin, self.full_shape, block, base + k), -1, "00:00:00.000"
             else:
-                fr = RoiFrame(block[k], self.origin, self.full_shape, block, k)
+                fr = RoiFrame(block[base + k], self.origin, self.full_shape, block, base + k)
                 num, ts = number, self.frame_number_to_timestamp(number)
                 self.next_frame_number += 1
                 if number < self.count:

@@ -93,7 +93,8 @@ def test_queue_uploads_the_readers_block_without_a_copy(tmp_path):
     q.push_list_of_frames(frames, numbers, stamps)
     made = []
     stack, (rx, ry), (Hc, Wc), backwards = stack_frames(q.get_queue(), CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
-    assert stack is frames[0].block and backwards and not made and (rx, ry, Hc, Wc) == (12, 12, 60, 120)
+    assert stack.ctypes.data == frames[0].block.ctypes.data and stack.shape[0] == 21 and np.shares_memory(stack, frames[0].block)
+    assert backwards and not made and (rx, ry, Hc, Wc) == (12, 12, 60, 120)
     for pos in range(21):                                  # queue position pos = block slot 20 - pos = frame 20 - pos of the clip
         np.testing.assert_array_equal(stack[20 - pos][ry:ry + Hc, rx:rx + Wc], clip[20 - pos][30:90, 40:160])
     # a shuffled queue (or frames of two windows) is staged instead
@@ -153,6 +154,36 @@ def test_counting_loop_over_a_roi_stream_equals_the_full_frame_run(tmp_path):
     events_c = pipeline.swift_counting_algorithm(RoiStreamReader(path), corners=corners)
     count_d, events_d = pipeline.count_swifts(list(clip), corners=corners)
     assert event_signature(events_c) == event_signature(events_d)
+
+
+def test_windows_read_ahead_lie_side_by_side_in_one_block(tmp_path):
+    """A reader that is read `ahead` windows at a time (the reader that segments ahead, windows_per_call) places those windows side by
+    side in ONE page-locked block: a batch of them, taken in reverse window order, is a contiguous piece of the block read backwards
+    -- stack_frames hands it over without a staging copy (round 4; before, every batch of a ROI stream was copied once more)."""
+    from swiftwatcher_amd.data_structures import stack_frames
+    clip = _clip(21 * 5 + 4, seed=6)
+    path = write_roi_stream(str(tmp_path / "clip.swkroi"), clip, CROP)
+    r = RoiStreamReader(path, ahead=3)
+    windows = [r.get_n_frames(21) for _ in range(6)]          # two blocks' worth; the last window is padded (duplicate + nulls)
+    made = []
+    for group in (windows[0:3], windows[3:6]):
+        blk = group[0][0][0].block
+        assert blk.shape[0] == 63 and all(f.block is blk for w in group for f in w[0])
+        assert [f.slot for w in group for f in w[0]] == list(range(63))
+        ordered = [f for w in reversed(group) for f in w[0][::-1]]          # segment_windows' batch order for such windows
+        stack, (rx, ry), (Hc, Wc), backwards = stack_frames(ordered, CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+        assert backwards and not made and stack.shape[0] == 63 and stack.ctypes.data == blk.ctypes.data
+        # the pixels are the file's: window k of the group = frames 21 k .. of the clip's stored rectangle
+        first = group[1][0][0]
+        np.testing.assert_array_equal(first[CROP[0][1]:CROP[1][1], CROP[0][0]:CROP[1][0]], clip[windows.index(group[1]) * 21][CROP[0][1]:CROP[1][1], CROP[0][0]:CROP[1][0]])
+    # a single window of such a block is still handed over as it lies
+    one = windows[1][0]
+    stack, _, _, backwards = stack_frames(one[::-1], CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert backwards and not made and stack.shape[0] == 21 and stack.ctypes.data == one[0].roi.ctypes.data
+    # in another order (windows not reversed) the batch is staged
+    stack_frames([f for w in windows[0:2] for f in w[0][::-1]], CROP, (24, 24), lambda shape: made.append(shape) or np.empty(shape, np.uint8))
+    assert len(made) == 1
+    r.close()
 
 
 @pytest.mark.gpu
