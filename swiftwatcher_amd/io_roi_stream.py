@@ -34,6 +34,26 @@ from . import _lib
 
 MAGIC = b"SWKROI1\n"
 _PIXELS_LOCK = threading.Lock()          # RoiFrame.__getitem__ against RoiFrame.detach (two threads of one reader's frames)
+# Page-locked blocks of closed readers, by (device, shape): pinning memory costs tens of milliseconds per 100 MB (a 4K ROI's ring of three
+# 8-window blocks is 600 MB: 40 ms of a 100-ms video), so a reader that is closed hands the blocks nobody looks at any more to the
+# next reader of the same geometry (one video after another on a GPU; a video played again).
+_BLOCK_POOL, _BLOCK_POOL_LOCK, _BLOCK_POOL_CAP = {}, threading.Lock(), 8
+
+
+def _take_block(shape, device):
+    with _BLOCK_POOL_LOCK:
+        free = _BLOCK_POOL.get((device, tuple(shape)))
+        if free:
+            return free.pop()
+    return _lib.pinned_empty(tuple(shape), np.uint8, device=device)
+
+
+def _give_blocks(blocks, device):
+    with _BLOCK_POOL_LOCK:
+        for b in blocks:
+            free = _BLOCK_POOL.setdefault((device, tuple(b.shape)), [])
+            if len(free) < _BLOCK_POOL_CAP:
+                free.append(b)
 
 
 def margin_rect(frame_hw, crop_region, min_seg_size=(24, 24)):
@@ -248,6 +268,17 @@ class RoiStreamReader:
                 self._jobs = None
             os.close(self._fd)
             self._fd = None
+            self._release_blocks()
+
+    def _release_blocks(self):
+        """Blocks no live frame looks into go to the pool of page-locked blocks (a frame still alive keeps its block to itself)."""
+        free = []
+        for blk, alive in zip(self._blocks, self._alive):
+            if not any(fr is not None and fr.block is blk for fr in (ref() for ref in alive)):
+                free.append(blk)
+        self._blocks, self._alive = [], []
+        if free:
+            _give_blocks(free, self.device)
 
     def __del__(self):
         try:
@@ -265,7 +296,8 @@ class RoiStreamReader:
         group = max(int(self.ahead), 1)
         if not self._blocks or self._blocks[0].shape[0] != group * n:
             ring = self.BLOCKS if group == 1 else max(3, -(-self.BLOCKS // group) + 2)
-            self._blocks = [_lib.pinned_empty((group * n,) + self.roi_shape, np.uint8, device=self.device) for _ in range(ring)]
+            self._release_blocks()
+            self._blocks = [_take_block((group * n,) + self.roi_shape, self.device) for _ in range(ring)]
             self._alive = [[] for _ in range(ring)]
             self._turn, self._used = 0, group          # (the first call below moves on to block 0)
             self._turn = len(self._blocks) - 1
@@ -277,7 +309,7 @@ class RoiStreamReader:
         live = [fr for fr in (ref() for ref in self._alive[b]) if fr is not None and fr.block is self._blocks[b]]
         if len(live) > (group * n) // 2 and len(self._blocks) < self.MAX_BLOCKS:
             # most of that block is still in use (its frames wait to be segmented, or sit in long tracks): a new block instead
-            self._blocks.insert(b, _lib.pinned_empty((group * n,) + self.roi_shape, np.uint8, device=self.device))
+            self._blocks.insert(b, _take_block((group * n,) + self.roi_shape, self.device))
             self._alive.insert(b, [])
         else:
             for fr in live:
