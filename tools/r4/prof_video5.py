@@ -37,6 +37,9 @@ def wrap(obj, name, tag):
         t0 = time.perf_counter(); r = fn(*a, **k); log.append((tag, t0, time.perf_counter())); return r
     setattr(obj, name, w)
 wrap(RoiStreamReader, "_fill", "fill")
+wrap(RoiStreamReader, "_block", "block")
+wrap(RoiStreamReader, "get_n_frames", "get_n")
+wrap(PresegmentingReader, "get_n_frames", "pre_get_n")
 wrap(ds, "stack_frames", "stack")
 wrap(ds, "window_segments", "objects")
 wrap(_lib.Context, "batch_run", "batch_run")
@@ -56,6 +59,6 @@ for tag, a, b in log:
     agg.setdefault(tag, [0, 0.0]); agg[tag][0] += 1; agg[tag][1] += b - a
 for tag, (c, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-12s calls %4d  total %7.2f ms" % (tag, c, s * 1e3))
-for tag, a, b in log:
-    if tag in ("batch_run", "clf_launch", "objects", "stack", "cut_boxes"):
+for tag, a, b in sorted(log, key=lambda r: r[1])[:40]:
+    if True:
         print("%-12s %8.2f -> %8.2f ms" % (tag, (a - t0) * 1e3, (b - t0) * 1e3))
