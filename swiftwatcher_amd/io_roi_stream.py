@@ -37,7 +37,7 @@ _PIXELS_LOCK = threading.Lock()          # RoiFrame.__getitem__ against RoiFrame
 # Page-locked blocks of closed readers, by (device, shape): pinning memory costs tens of milliseconds per 100 MB (a 4K ROI's ring of three
 # 8-window blocks is 600 MB: 40 ms of a 100-ms video), so a reader that is closed hands the blocks nobody looks at any more to the
 # next reader of the same geometry (one video after another on a GPU; a video played again).
-_BLOCK_POOL, _BLOCK_POOL_LOCK, _BLOCK_POOL_CAP = {}, threading.Lock(), 8
+_BLOCK_POOL, _BLOCK_POOL_LOCK, _BLOCK_POOL_BYTES = {}, threading.Lock(), 1 << 30          # at most 1 GiB kept page-locked for later readers
 
 
 _FILL_POOL = None
@@ -61,10 +61,12 @@ def _take_block(shape, device):
 
 def _give_blocks(blocks, device):
     with _BLOCK_POOL_LOCK:
+        held = sum(a.nbytes for free in _BLOCK_POOL.values() for a in free)
         for b in blocks:
-            free = _BLOCK_POOL.setdefault((device, tuple(b.shape)), [])
-            if len(free) < _BLOCK_POOL_CAP:
-                free.append(b)
+            if held + b.nbytes > _BLOCK_POOL_BYTES:
+                break          # (the rest is unpinned and freed with its last reference)
+            _BLOCK_POOL.setdefault((device, tuple(b.shape)), []).append(b)
+            held += b.nbytes
 
 
 def margin_rect(frame_hw, crop_region, min_seg_size=(24, 24)):
