@@ -189,6 +189,44 @@ class Frame:
         self.segments = [Segment(rp, self.frame_number, self.timestamp, seg)
                          for rp, seg in zip(regionprops_list, segment_images)]
 
+    def export_segments(self, min_seg_size, crop_region, export_dir):
+        """data_structures.py:65-113 (`--export`, debug output; host code, no GPU): per segment a PNG of the crop with the segment's box
+        tinted red (cv2.rectangle filled, both corners inclusive, blended 0.6 / 0.4 by cv2.addWeighted) under <export_dir>/overlay,
+        and the segment's >= min_seg_size cut from the full frame under <export_dir>.  Files are named like the reference's
+        ('"<video stem>"_<frame>_<label>_<segments in the frame>.png').  PNGs are written with Pillow (cv2 is not a dependency): the
+        pixels are cv2.imwrite's (BGR arrays stored as RGB images), the compressed bytes are not.  PARITY UNPINNED (cv2 arithmetic:
+        float32 blend, round half to even, restated)."""
+        import math
+        from pathlib import Path
+        from PIL import Image
+        export_dir = Path(export_dir)
+        (export_dir / "overlay").mkdir(parents=True, exist_ok=True)
+        color_img = np.asarray(self.processed_frames["crop"])
+        oy, ox = crop_region[0][1], crop_region[0][0]
+        for segment in self.segments:
+            name = '"{}"_{}_{}_{}.png'.format(self.src_video, self.frame_number, segment.label, len(self.segments))
+            bbox = list(segment.bbox)
+            overlay = color_img.copy()
+            r0, c0 = max(bbox[0], 0), max(bbox[1], 0)
+            overlay[r0:bbox[2] + 1, c0:bbox[3] + 1] = (0, 0, 255)                      # cv2.rectangle(..., -1): corners inclusive, BGR red
+            blend = overlay.astype(np.float32) * np.float32(0.6) + color_img.astype(np.float32) * np.float32(0.4)
+            output = np.clip(np.rint(blend), 0, 255).astype(np.uint8)
+            Image.fromarray(np.ascontiguousarray(output[..., ::-1])).save(str(export_dir / "overlay" / name))
+            h, w = bbox[2] - bbox[0], bbox[3] - bbox[1]
+            if h < min_seg_size[0]:
+                d = min_seg_size[0] - h
+                bbox[0] -= math.floor(d / 2)
+                bbox[2] += math.ceil(d / 2)
+            if w < min_seg_size[1]:
+                d = min_seg_size[1] - w
+                bbox[1] -= math.floor(d / 2)
+                bbox[3] += math.ceil(d / 2)
+            # (a box that leaves the frame's top / left is clamped like extract_segment_images here clamps it: INTEGRATION.md)
+            seg = self.frame[max(bbox[0] + oy, 0):max(bbox[2] + oy, 0), max(bbox[1] + ox, 0):max(bbox[3] + ox, 0)]
+            seg = np.asarray(seg)
+            if seg.size:
+                Image.fromarray(np.ascontiguousarray(seg[..., ::-1] if seg.ndim == 3 else seg)).save(str(export_dir / name))
+
 
 class Presegmented:
     """One window that a reader segmented ahead of the counting loop (io_frames.PresegmentingReader): the frames as get_n_frames handed

@@ -276,3 +276,37 @@ def test_a_batch_learns_its_own_generation_under_the_context_lock():
         t.join()
     assert sorted(g for g, _ in got) == [1, 2, 3, 4] and not ctx._lib.overlap
     ctx._h = None
+
+
+def test_export_segments_writes_the_reference_files(tmp_path):
+    """Frame.export_segments (data_structures.py:65-113, `--export`): file names, the tinted overlay (box corners inclusive, 0.6 / 0.4
+    blend) and the >= 24 x 24 cut from the FULL frame, read back from the PNGs (Pillow; cv2 is installed nowhere: PARITY UNPINNED)."""
+    from PIL import Image
+    from swiftwatcher_amd.data_structures import Frame, Segment
+    from swiftwatcher_amd.image_filtering import RegionProps
+    rng = np.random.default_rng(5)
+    full = rng.integers(0, 256, size=(120, 200, 3), dtype=np.uint8)
+    crop_region = [(40, 30), (160, 100)]
+    fr = Frame(full, 17, "00:00:00.567")
+    Frame.src_video = "clip 1"
+    try:
+        fr.processed_frames["crop"] = full[30:100, 40:160]
+        fr.segments = [Segment(RegionProps(1, (10, 20, 16, 30), (12.5, 24.0), 40), 17, "t", None),
+                       Segment(RegionProps(2, (50, 5, 69, 47), (60.0, 25.0), 500), 17, "t", None)]
+        fr.export_segments((24, 24), crop_region, tmp_path / "segments")
+    finally:
+        Frame.src_video = None
+    names = sorted(p.name for p in (tmp_path / "segments").glob("*.png"))
+    assert names == ['"clip 1"_17_1_2.png', '"clip 1"_17_2_2.png']
+    assert sorted(p.name for p in (tmp_path / "segments" / "overlay").glob("*.png")) == names
+    crop = full[30:100, 40:160].astype(np.float32)
+    ov = np.asarray(Image.open(tmp_path / "segments" / "overlay" / names[0]))[..., ::-1]          # back to BGR
+    exp = crop.copy()
+    box = np.zeros(crop.shape[:2], bool)
+    box[10:17, 20:31] = True
+    exp[box] = np.rint(0.6 * np.array([0, 0, 255], np.float32) + 0.4 * crop[box])
+    np.testing.assert_array_equal(ov, exp.astype(np.uint8))
+    seg = np.asarray(Image.open(tmp_path / "segments" / names[0]))[..., ::-1]
+    np.testing.assert_array_equal(seg, full[30 + 1:30 + 25, 40 + 13:40 + 37])          # 6 x 10 box grown to 24 x 24, cut from the full frame
+    seg2 = np.asarray(Image.open(tmp_path / "segments" / names[1]))[..., ::-1]
+    np.testing.assert_array_equal(seg2, full[30 + 48:30 + 72, 40 + 5:40 + 47])          # 19 rows grown by 2 + 3, 42 columns kept
