@@ -12,7 +12,7 @@ from . import image_filtering as img
 
 
 def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size=21, classifier=None, min_seg_size=(24, 24),
-                             device=0, keep_stages=False, windows_per_call=1, corners=None):
+                             device=0, keep_stages=False, windows_per_call=1, corners=None, export_dir=None):
     """Same call order as __main__.py:62-100.  corners = ((x1, y1), (x2, y2)) of the chimney's top edge: crop region
     and ROI mask are then generated from the video's first frame (:62-63) instead of being passed in.  Returns the tracker's detected events (lists of Segment objects,
     the structure the reference hands to event classification).  windows_per_call > 1 reads that many queue-fuls
@@ -81,6 +81,8 @@ def swift_counting_algorithm(reader, crop_region=None, roi_mask=None, queue_size
             tracker.link_matching_segments()
             tracker.check_for_events()
             tracker.cache_current_frame()
+            if export_dir is not None:                                         # :94-96 (--export): needs keep_stages=True (the "crop" image)
+                frame.export_segments(min_seg_size, crop_region, export_dir)
     return tracker.detected_events
 
 
