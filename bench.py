@@ -817,6 +817,8 @@ def main():
             return {"bound": "mfma", "bound_detail": "f64 execution unit (v_mfma_f64_16x16x4_f64 + f64 VALU share one pipe); HBM right behind",
                     "kernel": "ialm_pass", "achieved": round(f64_tflops, 2), "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(f64_tflops / F64_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                    # both fractions side by side (rounds 1 / 2 reported the HBM one as `frac`, round 3 on the f64-unit one)
+                    "frac_mfma": round(f64_tflops / F64_MATRIX_PEAK_TFLOPS, 4), "frac_hbm": round(achieved / HBM_PEAK_GBS, 4),
                     "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)},
                     "launches": int(pass_launches), "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 4),
                     "bytes_per_launch": int(total_bytes / max(pass_launches, 1)),
@@ -854,7 +856,11 @@ def main():
                        "classify": ("every segment through SqueezeNet-1.0 (fp32, eval mode, %s, %s): %d segments/step, %d kept"
                                     % ("full 224x224 network" if args.full_network else "receptive-field cropped", args.weights_note,
                                        kept_total[1], kept_total[0])) if clf else "off (--no-classify)",
-                       "parallelism": "windows sharded per GPU, no data-path collective"},
+                       "parallelism": "windows sharded per GPU, no data-path collective",
+                       # what changed in the synthetic workloads, by round (records of different revisions are not comparable line by line)
+                       "workload_revision": "r4: headline stream unchanged since r1 (12 birds 30-50 x 12-20 px); P3 since r3: 14 birds of the 1080p pixel "
+                                            "size; count_loop clip since r4: 14 small faint birds per frame (what model.pt keeps a share of), "
+                                            "classifier = model.pt's weights"},
             "redo_batches": int(redo), "redo_windows": int(ctx.redo_windows - redo_w0), "guard_windows": int(ctx.guard_windows),
             "refined_windows": dict(zip(("refined", "given_up"), ctx.refined_windows)),
             "per_rank": [{"rank": r, "frames": int(table[r, 2]), "frames_per_s": round(float(table[r, 2]) / max(float(rank_ms[r]) * 1e-6, 1e-9), 1),
