@@ -239,12 +239,21 @@ class CroppedSqueezeNet10:
         self.version = getattr(self, "version", 0) + 1          # new addresses: captured graphs of the old ones are void
         return self._buf
 
+    def _gpu_path(self, tiles):
+        return tiles.is_cuda and self.memory_format == torch.channels_last and all(
+            kind != "fire" or not (pad[0] or pad[1]) for kind, _, _, _, _, pad, _ in self.plan)
+
+    def reserve(self, batch):
+        """Persistent tiles for `batch` segments, made now (on the current stream)."""
+        self._buffers(batch)
+        if self.ring_sum.is_cuda:
+            self._aux_buffers(batch)
+
     @torch.no_grad()
     def __call__(self, tiles, row0=0):
         """tiles: (B, 3, 40, 40) float32 = rows/cols 92..131 of the normalised 224x224 input.  row0: first row of the persistent
         per-layer tiles this forward works in (two forwards on disjoint row ranges may run side by side on two streams)."""
-        if tiles.is_cuda and self.memory_format == torch.channels_last and all(
-                kind != "fire" or not (pad[0] or pad[1]) for kind, _, _, _, _, pad, _ in self.plan):
+        if self._gpu_path(tiles):
             with torch.cuda.device(tiles.device):            # the glue kernels go to this device's current stream
                 return self._forward_hip_glue(tiles, row0)
         if row0:
@@ -504,6 +513,9 @@ class SegmentClassifier:
         # that read it (a slot is handed to the library's stream again only after that event)
         self._slots = None
         self._lock = threading.RLock()          # one scoring at a time (see _scores_device)
+        # forwards of this many rows or more run as two chains on two streams (_forward_two_streams); 0 = never
+        self._split_rows = int(os.environ.get("SWK_CNN_SPLIT_ROWS", "2048")) if self.device.type == "cuda" else 0
+        self._side_stream = None
         self._graphs = {}
         self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
         self._graph_error = None
@@ -550,7 +562,32 @@ class SegmentClassifier:
         if self._cudnn_benchmark and (self.cropped is None or not self.cropped.own_kernels):
             with torch.backends.cudnn.flags(enabled=True, benchmark=True):
                 return self.cropped(x) if self.cropped is not None else self.model(x)
+        if (self._split_rows and x.shape[0] >= self._split_rows and self.cropped is not None and self.cropped.own_kernels
+                and self.cropped._gpu_path(x)):
+            return self._forward_two_streams(x)
         return self.cropped(x) if self.cropped is not None else self.model(x)
+
+    def _forward_two_streams(self, x):
+        """A large forward as two forwards on disjoint rows of the persistent tiles, the second on a side stream.  The kernels of a
+        forward alternate between the matrix pipe (3 x 3 expands, 70 % busy at 1 TB/s) and memory (squeezes, expand1x1: half the HBM
+        rate), and every one of its 34 launches ends with a tail of part-filled CUs; two chains fill each other's gaps: 13.86 against
+        14.66 ms per 8,192 rows (tools/r4/two_stream_forward.py; three chains 13.97, four 14.48).  Same kernels on the same rows:
+        the scores are the single chain's, up to the last bit of the 512 -> 2 head -- a library product whose summation order depends
+        on its row count (tools/r4/forward_sizes.py: 1 ulp for some row counts, with or without this split)."""
+        k = x.shape[0]
+        half = -(-k // 2 // 512) * 512
+        cur = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        self.cropped.reserve(k)                     # the tiles grow on THIS stream, before either half looks them up
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            hi = self.cropped(x[half:], row0=half)
+        lo = self.cropped(x[:half])
+        cur.wait_stream(side)
+        hi.record_stream(cur)
+        return torch.cat([lo, hi])
 
     def _forward_graphed(self, x):
         """A window's worth of segments (<= 512 rows) is some thirty kernels of a few microseconds each: launched one by one from

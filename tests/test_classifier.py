@@ -668,6 +668,32 @@ def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
 
 
 @pytest.mark.gpu
+def test_large_forward_on_two_streams_equals_one_chain():
+    """Forwards of 2,048 rows or more run as two chains on two streams over disjoint rows of the persistent tiles: the same kernels
+    on the same rows, so the scores are the one-chain forward's (the head, a library product, may move the last bit with its row
+    count).  Repeated with fresh contents in the same buffer, with a row count that does not halve evenly, and back to back with
+    smaller forwards on the main stream (the side stream's reads and writes are ordered against both)."""
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    clf = SegmentClassifier.from_state_dict(ref.random_state_dict(13), batch_size=4096)
+    assert clf._split_rows == 2048
+    g = torch.Generator(device="cpu").manual_seed(6)
+    for rows in (2048, 3584, 4096):
+        x = torch.randn((rows, 3, 40, 40), generator=g).to(clf.device).contiguous(memory_format=torch.channels_last)
+        for _ in range(2):
+            two = clf._forward(x).clone()
+            small = clf._forward(x[:192]).clone()                       # one chain, right behind the two
+            clf._split_rows = 0
+            one = clf._forward(x).clone()
+            clf._split_rows = 2048
+            np.testing.assert_allclose(two.cpu().numpy(), one.cpu().numpy(), atol=1e-6, rtol=1e-6)
+            np.testing.assert_allclose(small.cpu().numpy(), one[:192].cpu().numpy(), atol=1e-6, rtol=1e-6)
+            assert torch.equal(two.argmax(dim=1), one.argmax(dim=1))
+            x.mul_(-0.5)
+    assert clf._side_stream is not None
+
+
+@pytest.mark.gpu
 def test_fused_maxpool_squeeze_kernel_against_torch():
     """swk_nhwc_maxpool3s2_conv1x1_bias_relu_place (MaxPool2d(3, 2) + a Fire module's squeeze + bias + ReLU + placement as one kernel)
     against torch on the network's three pool -> squeeze pairs (96 -> 16 on 17 x 17, 256 -> 32 on 17 x 17, 512 -> 64 on 19 x 19) and
