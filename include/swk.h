@@ -268,6 +268,13 @@ int32_t swk_nhwc_bias_relu_place(void *stream, const float *src, int32_t n, int3
                                  int32_t crop_x, int32_t h, int32_t w, const float *bias, float *dst, int32_t dH, int32_t dW,
                                  int32_t dC, int32_t off_y, int32_t off_x, int32_t c_off);
 int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h, int32_t w, int32_t c, float *dst);
+/* head2_relu_mean: the classifier's two-class head (Conv2d(c, 2, 1), ReLU, AdaptiveAvgPool2d(1); the reference re-heads torchvision's
+ * SqueezeNet this way, segment_classification.py:47-67) over the px live positions of the last Fire's output, x [n][px][c]:
+ *   out[n][k] = (sum_p max(sum_ch x[n][p][ch] w[k][ch] + bias[k], 0) + ring[k]) / n_pos
+ * ring[k] = the head's sum over the positions that do not depend on the segment, n_pos = all positions.  c in {256, 512, 768, 1024}.
+ * Fixed summation order: a segment's scores do not depend on the batch it is in. */
+int32_t swk_nhwc_head2_relu_mean(void *stream, const float *x, int32_t n, int32_t px, int32_t c, const float *w, const float *bias,
+                                 const float *ring, float n_pos, float *out);
 /* conv7x7s2_bias_relu: the network's first convolution (Conv2d(3, 96, 7, stride 2), no padding) with bias and ReLU on the f32 matrix
  * cores, for the m x m outputs starting at output (lo, lo) of a side x side channels-last input:
  *   dst[n][y][x][co] = max(sum src[n][2 (lo + y) + dy][2 (lo + x) + dx][c] * weight[co][c][dy][dx] + bias[co], 0)
@@ -287,10 +294,13 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
 
 /* maxpool3s2 + conv1x1_bias_relu_place as ONE kernel (a MaxPool2d(3, 2) followed by a Fire module's squeeze: the pooled tensor never
  * goes to memory): src [n][t][t][cin] (cin a multiple of 32), pooled size p = (t - 3) / 2 + 1 (p * p <= 96), weight [cout][cin] with
- * cout <= 64 a multiple of 4;  dst[n][off_y + y][off_x + x][co] = max(sum_ci weight[co][ci] max_{3x3, stride 2} src + bias[co], 0). */
+ * cout <= 64 a multiple of 4;  dst[n][off_y + y][off_x + x][co] = max(sum_ci weight[co][ci] max_{3x3, stride 2} src + bias[co], 0).
+ * ring (or NULL): ONE tile [t][t][cin] whose pixels outside the square [live_lo, live_lo + live_n)^2 equal those of every tile of src
+ * (the receptive-field cropped network's tiles carry a ring of segment-independent values): those pixels are then read from it, so
+ * that the ring of n tiles is not fetched n times. */
 int32_t swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight,
                                                     const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC,
-                                                    int32_t off_y, int32_t off_x);
+                                                    int32_t off_y, int32_t off_x, const float *ring, int32_t live_lo, int32_t live_n);
 
 
 /* conv3x3_bias_relu_place: the 3 x 3 expand convolution of a Fire module as a VALID convolution over the t x t squeeze tile

@@ -61,6 +61,77 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const float4 *__restrict__ s
     }
 }
 
+// The classifier's head (Dropout is the identity in eval mode, then Conv2d(512, 2, 1), ReLU, AdaptiveAvgPool2d(1): torchvision's
+// SqueezeNet classifier as segment_classification.py:47-67 of the reference re-heads it) over the live square of the last Fire's
+// output, [n][px][c] channels-last:
+//     out[n][k] = (sum_p max(sum_ch x[n][p][ch] w[k][ch] + bias[k], 0) + ring[k]) / n_pos,       k = 0, 1
+// (ring: the sum over the positions outside the square, which do not depend on the segment).  One workgroup per segment, four waves;
+// a wave takes pixels wave, wave + 4, ...: lane l holds the weights of channels 256 j + 4 l .. + 3, multiplies its float4s, the two
+// sums cross the wave as a butterfly, pixels add up in order, the four waves in order: the summation order is a function of the
+// shapes alone, so a segment's score does not depend on the batch it is scored in (the library product this replaces picked its
+// kernel, and with it the last bit, by the row count).  Memory-bound: 4 c bytes per pixel read once.
+template <int CJ>
+__global__ __launch_bounds__(256) void k_head2_relu_mean(const float *__restrict__ x, int px, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, const float *__restrict__ ring, float inv_pos,
+                                                         float *__restrict__ out)
+{
+    constexpr int C = 256 * CJ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *xp = x + (int64_t)blockIdx.x * px * C + 4 * lane;
+    float4 w0[CJ], w1[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        w0[j] = *(const float4 *)(w + 256 * j + 4 * lane);
+        w1[j] = *(const float4 *)(w + C + 256 * j + 4 * lane);
+    }
+    const float b0 = bias[0], b1 = bias[1];
+    float s0 = 0.0f, s1 = 0.0f;
+    auto dot = [&](const float4 (&v)[CJ], float &d0, float &d1) {
+        d0 = 0.0f; d1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            d0 = fmaf(v[j].x, w0[j].x, d0); d0 = fmaf(v[j].y, w0[j].y, d0); d0 = fmaf(v[j].z, w0[j].z, d0); d0 = fmaf(v[j].w, w0[j].w, d0);
+            d1 = fmaf(v[j].x, w1[j].x, d1); d1 = fmaf(v[j].y, w1[j].y, d1); d1 = fmaf(v[j].z, w1[j].z, d1); d1 = fmaf(v[j].w, w1[j].w, d1);
+        }
+    };
+    auto across = [&](float v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    };
+    // two pixels per trip: their loads leave together
+    int p = wave;
+    for (; p + 4 < px; p += 8) {
+        float4 va[CJ], vb[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            va[j] = *(const float4 *)(xp + (int64_t)p * C + 256 * j);
+            vb[j] = *(const float4 *)(xp + (int64_t)(p + 4) * C + 256 * j);
+        }
+        float a0, a1, c0, c1;
+        dot(va, a0, a1);
+        dot(vb, c0, c1);
+        s0 += fmaxf(across(a0) + b0, 0.0f); s1 += fmaxf(across(a1) + b1, 0.0f);
+        s0 += fmaxf(across(c0) + b0, 0.0f); s1 += fmaxf(across(c1) + b1, 0.0f);
+    }
+    if (p < px) {
+        float4 va[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) va[j] = *(const float4 *)(xp + (int64_t)p * C + 256 * j);
+        float a0, a1;
+        dot(va, a0, a1);
+        s0 += fmaxf(across(a0) + b0, 0.0f); s1 += fmaxf(across(a1) + b1, 0.0f);
+    }
+    __shared__ float part[4][2];
+    if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        const float t = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+        out[(int64_t)blockIdx.x * 2 + k] = (t + ring[k]) * inv_pos;
+    }
+}
+
 }  // namespace swk
 
 #pragma GCC visibility push(default)
@@ -88,6 +159,23 @@ int32_t swk_nhwc_maxpool3s2(void *stream, const float *src, int32_t n, int32_t h
     const int64_t total = (int64_t)n * oh * (c / 4);
     hipLaunchKernelGGL(swk::k_maxpool3s2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)src, h, w, c / 4, (float4 *)dst, oh, ow, total);
+    return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
+}
+
+int32_t swk_nhwc_head2_relu_mean(void *stream, const float *x, int32_t n, int32_t px, int32_t c, const float *w, const float *bias,
+                                 const float *ring, float n_pos, float *out)
+{
+    if (!x || !w || !bias || !ring || !out || n < 1 || px < 1 || !(n_pos > 0.0f) || (((uintptr_t)x | (uintptr_t)w) & 15)) return SWK_ERR_ARG;
+    if (c != 256 && c != 512 && c != 768 && c != 1024) return SWK_ERR_ARG;
+    const dim3 grid((unsigned)n), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv = 1.0f / n_pos;
+    switch (c / 256) {
+    case 1: hipLaunchKernelGGL(swk::k_head2_relu_mean<1>, grid, block, 0, st, x, px, w, bias, ring, inv, out); break;
+    case 2: hipLaunchKernelGGL(swk::k_head2_relu_mean<2>, grid, block, 0, st, x, px, w, bias, ring, inv, out); break;
+    case 3: hipLaunchKernelGGL(swk::k_head2_relu_mean<3>, grid, block, 0, st, x, px, w, bias, ring, inv, out); break;
+    default: hipLaunchKernelGGL(swk::k_head2_relu_mean<4>, grid, block, 0, st, x, px, w, bias, ring, inv, out); break;
+    }
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 

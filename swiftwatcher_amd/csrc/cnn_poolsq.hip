@@ -23,7 +23,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 template <int PT, int NB>
 __global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__restrict__ src, int n, int T, int C, int P, const float *__restrict__ wgt,
                                                                const float *__restrict__ bias, int S, float *__restrict__ dst, int dH, int dW, int dC,
-                                                               int off_y, int off_x)
+                                                               int off_y, int off_x, const float *__restrict__ ring, int live_lo, int live_n)
 {
     constexpr int NW = PT * NB, NT = 64 * NW, PP = 32 * PT + 1, SP = 32 * NB + 1, KC = 32;
     __shared__ float sB[2][KC * PP];          // pooled pixels of a chunk: [channel k][pixel]
@@ -44,20 +44,29 @@ __global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__re
             a[0] = w.x; a[SP] = w.y; a[2 * SP] = w.z; a[3 * SP] = w.w;
         }
         // ---- pooled pixels: (pixel, quad of k) items ----
-        const float *base = src + (int64_t)seg * T * rs + kb;
+        // pixels outside the live square [live_lo, live_lo + live_n)^2 hold the same values in every segment's tile (the ring the
+        // tiles were created with): they are read from ONE tile (`ring`, cache-resident) instead of the segment's own -- at pool2 /
+        // pool3 half of a tile's bytes.  ring == src's first tile and live = the whole tile when the caller has no ring.
+        const float *base = src + (int64_t)seg * T * rs + kb, *rbase = ring + kb;
         for (int i = tid; i < 32 * PT * 8; i += NT) {
             const int p = i >> 3, q = i & 7;
             float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < npix) {
                 const int py = p / P, px = p - py * P;
-                const float *s0 = base + (int64_t)(2 * py) * rs + (int64_t)(2 * px) * C + 4 * q;
-                m = *(const float4 *)s0;
+                const int64_t o0 = (int64_t)(2 * py) * rs + (int64_t)(2 * px) * C + 4 * q;
+                bool iny[3], inx[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    iny[d] = (unsigned)(2 * py + d - live_lo) < (unsigned)live_n;
+                    inx[d] = (unsigned)(2 * px + d - live_lo) < (unsigned)live_n;
+                }
+                m = *(const float4 *)((iny[0] && inx[0] ? base : rbase) + o0);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         if (dy == 0 && dx == 0) continue;
-                        const float4 v = *(const float4 *)(s0 + dy * rs + dx * C);
+                        const float4 v = *(const float4 *)((iny[dy] && inx[dx] ? base : rbase) + o0 + dy * rs + dx * C);
                         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                     }
             }
@@ -105,11 +114,11 @@ __global__ __launch_bounds__(64 * PT * NB) void k_pool_squeeze(const float *__re
 
 template <int PT, int NB>
 static int launch_pool_squeeze(hipStream_t s, const float *src, int n, int T, int C, int P, const float *wgt, const float *bias, int S, float *dst,
-                               int dH, int dW, int dC, int off_y, int off_x)
+                               int dH, int dW, int dC, int off_y, int off_x, const float *ring, int live_lo, int live_n)
 {
     int blocks = n < 256 * 8 ? n : 256 * 8;          // persistent over the segments beyond a few workgroups per CU
     hipLaunchKernelGGL((k_pool_squeeze<PT, NB>), dim3((unsigned)blocks), dim3(64 * PT * NB), 0, s, src, n, T, C, P, wgt, bias, S, dst, dH, dW, dC,
-                       off_y, off_x);
+                       off_y, off_x, ring, live_lo, live_n);
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
@@ -120,17 +129,19 @@ extern "C" {
 
 int32_t swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(void *stream, const float *src, int32_t n, int32_t t, int32_t cin, const float *weight,
                                                     const float *bias, int32_t cout, float *dst, int32_t dH, int32_t dW, int32_t dC,
-                                                    int32_t off_y, int32_t off_x)
+                                                    int32_t off_y, int32_t off_x, const float *ring, int32_t live_lo, int32_t live_n)
 {
     if (!src || !weight || !bias || !dst || n < 1 || t < 3 || cin < 32 || (cin & 31) || cout < 4 || (cout & 3) || cout > 64 || (dC & 3) ||
         off_y < 0 || off_x < 0 || (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)weight | (uintptr_t)bias) & 15))
         return SWK_ERR_ARG;
+    if (!ring) { ring = src; live_lo = 0; live_n = t; }
+    if (live_lo < 0 || live_n < 0 || live_lo + live_n > t || ((uintptr_t)ring & 15)) return SWK_ERR_ARG;
     const int P = (t - 3) / 2 + 1;
     if (off_y + P > dH || off_x + P > dW || cout > dC || P * P > 96) return SWK_ERR_ARG;
     using namespace swk;
     hipStream_t s = (hipStream_t)stream;
     const int PT = (P * P + 31) / 32, NB = (cout + 31) / 32;
-#define SWK_PS_ARGS s, src, n, t, cin, P, weight, bias, cout, dst, dH, dW, dC, off_y, off_x
+#define SWK_PS_ARGS s, src, n, t, cin, P, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, ring, live_lo, live_n
     if (PT == 1 && NB == 1) return launch_pool_squeeze<1, 1>(SWK_PS_ARGS);
     if (PT == 2 && NB == 1) return launch_pool_squeeze<2, 1>(SWK_PS_ARGS);
     if (PT == 3 && NB == 1) return launch_pool_squeeze<3, 1>(SWK_PS_ARGS);

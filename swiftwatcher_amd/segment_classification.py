@@ -168,6 +168,7 @@ class CroppedSqueezeNet10:
         # The two cross-checks the tests keep: own_kernels = False routes every convolution through MIOpen (+ the placement kernel),
         # winograd = False runs the 3x3 expands on the direct kernel (csrc/cnn_conv3x3.hip) instead of F(2x2, 3x3).
         self.own_kernels = os.environ.get("SWK_OWN_CNN_KERNELS", "1") == "1"
+        self._head = None
         self.winograd = True
         # max-pool + the squeeze behind it as one kernel (csrc/cnn_poolsq.hip): the pooled tensor never goes to memory
         self.fuse_pool = os.environ.get("SWK_FUSE_POOL", "1") == "1"
@@ -355,11 +356,13 @@ class CroppedSqueezeNet10:
             if rc:
                 raise RuntimeError("swk_nhwc_maxpool3s2 failed (%d)" % rc)
 
-        def pool_squeeze(src, conv, dest, off):
+        def pool_squeeze(src, conv, dest, off, ring=None, live=(0, 0)):
+            # ring: the tile whose ring every tile of src shares (written once, _buffers): only the live square is read per segment
             wgt = conv.weight.reshape(conv.out_channels, conv.in_channels)
             rc = lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, src.data_ptr(), k, src.shape[2], src.shape[1], wgt.data_ptr(),
                                                                  conv.bias.data_ptr(), conv.out_channels, dest.data_ptr(), dest.shape[2],
-                                                                 dest.shape[3], dest.shape[1], off, off)
+                                                                 dest.shape[3], dest.shape[1], off, off,
+                                                                 None if ring is None else ring.data_ptr(), live[0], live[1])
             if rc:
                 raise RuntimeError("swk_nhwc_maxpool3s2_conv1x1_bias_relu_place failed (%d)" % rc)
 
@@ -382,6 +385,7 @@ class CroppedSqueezeNet10:
             place(e, conv1.bias, c1buf, a, b - a, 0, 0)
         fuse = self.fuse_pool and self.own_kernels
         to_pool = c1buf               # a tensor whose max-pool the next squeeze reads (fused into it), or None
+        pool_ring, pool_live = None, (0, 0)        # conv1's output has no ring; the pool tiles behind fire4 and fire8 do
         x = aux["pool_in"][rows]
         if not fuse:
             pool(c1buf, x)
@@ -390,7 +394,7 @@ class CroppedSqueezeNet10:
             if kind == "pool":
                 x = aux["pool_out"][pi][rows]
                 if fuse:
-                    to_pool = bufs[j][rows]
+                    to_pool, pool_ring, pool_live = bufs[j][rows], bufs[j][0:1], (off, n)
                 else:
                     pool(bufs[j][rows], x)
                 pi += 1
@@ -407,7 +411,7 @@ class CroppedSqueezeNet10:
                 # (csrc/cnn_conv1x1.hip)
                 if fuse and to_pool is not None:
                     assert (to_pool.shape[2] - 3) // 2 + 1 == n
-                    pool_squeeze(to_pool, layer.squeeze, sq, off)
+                    pool_squeeze(to_pool, layer.squeeze, sq, off, pool_ring, pool_live)
                     to_pool = None
                 else:
                     conv1x1(x, 0, n, layer.squeeze, sq, off, 0)
@@ -427,7 +431,19 @@ class CroppedSqueezeNet10:
         # the 512 -> 2 head (1 x 1 convolution + ReLU + spatial sum) as a plain matrix product over the channels-last pixels: no
         # convolution library on this path, hence no kernel search per batch shape
         head = m.classifier[1]
-        px = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])                       # (B * 11 * 11, 512): a view of the NHWC memory
+        if self.own_kernels and head.out_channels == 2 and x.shape[1] in (256, 512, 768, 1024) and x.is_contiguous(memory_format=cl):
+            # the head as one kernel with a fixed summation order (csrc/cnn_aux.hip): scores that do not depend on the batch's row count
+            if self._head is None:
+                self._head = (head.weight.detach().reshape(2, -1).contiguous(), head.bias.detach().contiguous(),
+                              self.ring_sum.reshape(-1).contiguous())
+            hw, hb, ring = self._head
+            out = torch.empty((k, 2), dtype=torch.float32, device=x.device)
+            rc = lib.swk_nhwc_head2_relu_mean(stream, x.data_ptr(), k, x.shape[2] * x.shape[3], x.shape[1], hw.data_ptr(), hb.data_ptr(),
+                                              ring.data_ptr(), self.n_pos, out.data_ptr())
+            if rc:
+                raise RuntimeError("swk_nhwc_head2_relu_mean failed (%d)" % rc)
+            return out
+        px = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])                       # (B * live positions, 512): a view of the NHWC memory
         s = torch.relu(torch.nn.functional.linear(px, head.weight.view(head.out_channels, -1), head.bias))
         s = s.view(k, -1, head.out_channels).sum(dim=1)
         return (s + self.ring_sum) / self.n_pos
@@ -514,7 +530,7 @@ class SegmentClassifier:
         self._slots = None
         self._lock = threading.RLock()          # one scoring at a time (see _scores_device)
         # forwards of this many rows or more run as two chains on two streams (_forward_two_streams); 0 = never
-        self._split_rows = int(os.environ.get("SWK_CNN_SPLIT_ROWS", "2048")) if self.device.type == "cuda" else 0
+        self._split_rows = int(os.environ.get("SWK_CNN_SPLIT_ROWS", "1024")) if self.device.type == "cuda" else 0
         self._side_stream = None
         self._graphs = {}
         self._use_graphs = self.device.type == "cuda" and os.environ.get("SWK_HIP_GRAPHS", "1") == "1"
@@ -571,9 +587,9 @@ class SegmentClassifier:
         """A large forward as two forwards on disjoint rows of the persistent tiles, the second on a side stream.  The kernels of a
         forward alternate between the matrix pipe (3 x 3 expands, 70 % busy at 1 TB/s) and memory (squeezes, expand1x1: half the HBM
         rate), and every one of its 34 launches ends with a tail of part-filled CUs; two chains fill each other's gaps: 13.86 against
-        14.66 ms per 8,192 rows (tools/r4/two_stream_forward.py; three chains 13.97, four 14.48).  Same kernels on the same rows:
-        the scores are the single chain's, up to the last bit of the 512 -> 2 head -- a library product whose summation order depends
-        on its row count (tools/r4/forward_sizes.py: 1 ulp for some row counts, with or without this split)."""
+        14.66 ms per 8,192 rows (tools/r4/two_stream_forward.py; three chains 13.97, four 14.48; tools/r4/chunked_forward.py: 2,048 rows
+        as 2 x 1,024 take 9 % less than as one chain, 1,024 as 2 x 512 8 % less; window-sized forwards gain nothing, see _forward_graphed).  Same kernels on the same rows, the
+        head included (swk_nhwc_head2_relu_mean sums in an order fixed by the shapes): the scores are the single chain's bit for bit."""
         k = x.shape[0]
         half = -(-k // 2 // 512) * 512
         cur = torch.cuda.current_stream(self.device)

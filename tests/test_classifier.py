@@ -669,28 +669,68 @@ def test_graph_replay_of_window_sized_forwards_equals_the_eager_forward():
 
 @pytest.mark.gpu
 def test_large_forward_on_two_streams_equals_one_chain():
-    """Forwards of 2,048 rows or more run as two chains on two streams over disjoint rows of the persistent tiles: the same kernels
-    on the same rows, so the scores are the one-chain forward's (the head, a library product, may move the last bit with its row
-    count).  Repeated with fresh contents in the same buffer, with a row count that does not halve evenly, and back to back with
+    """Forwards of 1,024 rows or more run as two chains on two streams over disjoint rows of the persistent tiles: the same kernels
+    on the same rows, so the scores are the one-chain forward's bit for bit.  Repeated with fresh contents in the same buffer, with a row count that does not halve evenly, and back to back with
     smaller forwards on the main stream (the side stream's reads and writes are ordered against both)."""
     from swiftwatcher_amd.segment_classification import SegmentClassifier
     from oracle import classifier_ref as ref
     clf = SegmentClassifier.from_state_dict(ref.random_state_dict(13), batch_size=4096)
-    assert clf._split_rows == 2048
+    assert clf._split_rows == 1024
     g = torch.Generator(device="cpu").manual_seed(6)
-    for rows in (2048, 3584, 4096):
+    for rows in (1024, 1536, 3584, 4096):
         x = torch.randn((rows, 3, 40, 40), generator=g).to(clf.device).contiguous(memory_format=torch.channels_last)
         for _ in range(2):
             two = clf._forward(x).clone()
             small = clf._forward(x[:192]).clone()                       # one chain, right behind the two
             clf._split_rows = 0
             one = clf._forward(x).clone()
-            clf._split_rows = 2048
-            np.testing.assert_allclose(two.cpu().numpy(), one.cpu().numpy(), atol=1e-6, rtol=1e-6)
-            np.testing.assert_allclose(small.cpu().numpy(), one[:192].cpu().numpy(), atol=1e-6, rtol=1e-6)
-            assert torch.equal(two.argmax(dim=1), one.argmax(dim=1))
+            clf._split_rows = 1024
+            assert torch.equal(two, one) and torch.equal(small, one[:192]), rows
             x.mul_(-0.5)
     assert clf._side_stream is not None
+
+
+@pytest.mark.gpu
+def test_head_kernel_against_torch_and_batch_independence():
+    """swk_nhwc_head2_relu_mean = Conv2d(c, 2, 1) + ReLU + mean over all positions (the ring's share added as a constant), against
+    float64 torch; and the property it was written for: a segment's scores are bit-identical whatever batch it is scored in."""
+    from swiftwatcher_amd import _lib
+    from swiftwatcher_amd.segment_classification import SegmentClassifier
+    from oracle import classifier_ref as ref
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(8)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for c, side, n in ((512, 9, 37), (256, 1, 3), (1024, 4, 5), (768, 11, 2)):
+        x = torch.randn((n, c, side, side), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn((2, c), generator=g) * 0.05).to(dev)
+        b = torch.randn((2,), generator=g).to(dev)
+        ring = torch.randn((2,), generator=g).to(dev)
+        out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        n_pos = float(side * side + 40)
+        rc = lib.swk_nhwc_head2_relu_mean(stream, x.data_ptr(), n, side * side, c, w.data_ptr(), b.data_ptr(), ring.data_ptr(), n_pos, out.data_ptr())
+        assert rc == 0
+        want = (torch.relu(torch.einsum("nchw,kc->nkhw", x.double(), w.double()) + b.double().view(1, 2, 1, 1)).sum(dim=(2, 3)) + ring.double()) / n_pos
+        np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-6)
+        assert lib.swk_nhwc_head2_relu_mean(stream, x.data_ptr(), n, side * side, c + 4, w.data_ptr(), b.data_ptr(), ring.data_ptr(), n_pos, out.data_ptr()) != 0
+    clf = SegmentClassifier.from_state_dict(ref.random_state_dict(14), batch_size=4096)
+    x = torch.randn((2752, 3, 40, 40), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    whole = clf._forward(x).clone()
+    for k, row0 in ((96, 0), (33, 64), (2720, 32), (1, 2751)):
+        part = clf.cropped(x[row0:row0 + k], row0=row0 if k > 1 else 0)
+        assert torch.equal(part, whole[row0:row0 + k]), (k, row0)
+    # what the shared-ring reads of the pool + squeeze kernel rely on: outside its live square every segment's pool tile is the first one's
+    bufs, _ = clf.cropped._buf
+    pools = 0
+    for j, (kind, layer, tile, off, n, pad, crop) in enumerate(clf.cropped.plan):
+        if kind == "pool":
+            t = bufs[j].clone()
+            t[:, :, off:off + n, off:off + n] = 0
+            assert torch.equal(t, t[0:1].expand_as(t)) and 0 < n < t.shape[2]
+            live = bufs[j][:2752, :, off:off + n, off:off + n]
+            assert not torch.equal(live[0], live[1])
+            pools += 1
+    assert pools == 2
 
 
 @pytest.mark.gpu
@@ -718,7 +758,7 @@ def test_fused_maxpool_squeeze_kernel_against_torch():
         exp[:, :cout, off:off + p, off:off + p] = y
         torch.cuda.synchronize()
         rc = lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), n, t, cin, wgt.reshape(cout, cin).contiguous().data_ptr(),
-                                                             bias.data_ptr(), cout, dst.data_ptr(), dH, dH, dC, off, off)
+                                                             bias.data_ptr(), cout, dst.data_ptr(), dH, dH, dC, off, off, None, 0, 0)
         assert rc == 0, (rc, n, cin, cout, t)
         torch.cuda.synchronize()
         scale = max(float(y.abs().max()), 1.0)
@@ -726,10 +766,35 @@ def test_fused_maxpool_squeeze_kernel_against_torch():
         mask = torch.ones_like(dst, dtype=torch.bool)
         mask[:, :cout, off:off + p, off:off + p] = False
         assert bool((dst[mask] == -7.0).all())
+    # a ring shared by every tile: pixels outside the live square come from ONE tile, the segments' own copies are not read (they hold
+    # NaN here), and that tile's live square is not read either
+    for n, cin, cout, t, lo, ln in ((37, 256, 32, 17, 2, 12), (300, 512, 64, 19, 3, 14), (5, 96, 16, 17, 0, 17), (9, 64, 8, 9, 4, 1), (3, 64, 8, 9, 2, 0)):
+        full = torch.randn((n, cin, t, t), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        inside = torch.zeros((1, 1, t, t), dtype=torch.bool, device=dev)
+        inside[:, :, lo:lo + ln, lo:lo + ln] = True
+        full = torch.where(inside, full, full[0:1]).contiguous(memory_format=torch.channels_last)      # what a forward leaves in the tiles
+        nan = torch.full_like(full, float("nan"))
+        src = torch.where(inside, full, nan).contiguous(memory_format=torch.channels_last)
+        ring = torch.where(inside, nan[0:1], full[0:1]).contiguous(memory_format=torch.channels_last)
+        wgt = (torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5).to(dev)
+        bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+        p = (t - 3) // 2 + 1
+        outs = []
+        for s_, r_, a_, b_ in ((full, None, 0, 0), (src, ring, lo, ln)):
+            dst = torch.zeros((n, cout, p, p), device=dev).contiguous(memory_format=torch.channels_last)
+            rc = lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, s_.data_ptr(), n, t, cin, wgt.reshape(cout, cin).contiguous().data_ptr(),
+                                                                 bias.data_ptr(), cout, dst.data_ptr(), p, p, cout, 0, 0,
+                                                                 None if r_ is None else r_.data_ptr(), a_, b_)
+            assert rc == 0
+            outs.append(dst)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(outs[1]).any()) and torch.equal(outs[0], outs[1]), (n, cin, t, lo, ln)
+    assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 17, 96, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
+                                                           8, 8, 16, 0, 0, x.data_ptr(), 5, 13) != 0   # live square leaves the tile
     assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 17, 48, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
-                                                           8, 8, 16, 0, 0) != 0          # cin not a multiple of 32
+                                                           8, 8, 16, 0, 0, None, 0, 0) != 0          # cin not a multiple of 32
     assert lib.swk_nhwc_maxpool3s2_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 23, 96, wgt.data_ptr(), bias.data_ptr(), 16, dst.data_ptr(),
-                                                           11, 11, 16, 0, 0) != 0        # 121 pooled pixels: more than three pixel tiles
+                                                           11, 11, 16, 0, 0, None, 0, 0) != 0        # 121 pooled pixels: more than three pixel tiles
 
 
 @pytest.mark.gpu

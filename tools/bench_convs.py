@@ -55,7 +55,8 @@ def describe(name, a):
     if name == "swk_nhwc_maxpool3s2_conv1x1_bias_relu_place":
         n, t, cin, cout = a[2], a[3], a[4], a[7]
         p = (t - 3) // 2 + 1
-        return "p+1x1 %3d->%3d %2dx%2d" % (cin, cout, p, p), n * p * p * cin * cout, 4 * n * (t * t * cin + p * p * cout)
+        live = a[16] if len(a) > 16 and a[14] else t          # with a shared ring only the live square is fetched per segment
+        return "p+1x1 %3d->%3d %2dx%2d" % (cin, cout, p, p), n * p * p * cin * cout, 4 * n * (live * live * cin + p * p * cout)
     if name == "swk_nhwc_maxpool3s2":
         n, h, w, c = a[2], a[3], a[4], a[5]
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
