@@ -877,7 +877,7 @@ def main():
             res["roofline_cnn"] = {
                 "bound": "mfma",
                 "kernel": "SqueezeNet-1.0 forward, receptive-field cropped: the library's 1x1 / 3x3 / Winograd F(2x2,3x3) kernels on "
-                          "v_mfma_f32_32x32x2_f32, conv1 on the library's 7x7 kernel, pools inside the squeezes, the 512 -> 2 head a matrix product (no MIOpen on the path); torch.cuda events on torch's stream",
+                          "v_mfma_f32_32x32x2_f32, conv1 on the library's 7x7 kernel, pools inside the squeezes, the 512 -> 2 head one kernel with a fixed summation order (no MIOpen, no BLAS on the path); forwards of 1,024 rows or more as two chains on two streams over disjoint rows; torch.cuda events on torch's stream around each forward",
                 # achieved = the multiply-accumulates the kernels execute (Winograd: 16 per 2x2 outputs instead of 36): what the
                 # matrix pipe really does; direct_equivalent prices the same outputs as direct convolutions
                 "achieved": tf(flop), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -64,6 +64,9 @@ def describe(name, a):
     if name == "swk_nhwc_conv7x7s2_bias_relu":
         n, side, m = a[2], a[3], a[5]
         return "7x7s2  3-> 96 %2dx%2d" % (m, m), n * m * m * 147 * 96, 4 * n * (side * side * 3 + m * m * 96)
+    if name == "swk_nhwc_head2_relu_mean":
+        n, px, c = a[2], a[3], a[4]
+        return "head %3d->  2 %3d px" % (c, px), n * px * c * 2, 4 * n * px * c
     if name == "swk_nhwc_bias_relu_place":
         n, c, h, w = a[2], a[5], a[8], a[9]
         return "place %3d %2dx%2d" % (c, h, w), 0, 8 * n * c * h * w
@@ -83,7 +86,7 @@ def main():
     timed = TimedLib(_lib.load())
     _lib.load = lambda: timed
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn((batch, 3, 40, 40), generator=g).cuda()
+    x = torch.randn((batch, 3, 40, 40), generator=g).cuda().contiguous(memory_format=torch.channels_last)
     net = clf.cropped
     with torch.no_grad():
         for _ in range(2):
@@ -98,6 +101,17 @@ def main():
             whole.append((e0, e1))
         torch.cuda.synchronize()
         whole_ms = float(np.mean([a.elapsed_time(b) for a, b in whole]))
+        # the classifier's own entry: two chains on two streams from 1,024 rows (SegmentClassifier._forward_two_streams)
+        for _ in range(2):
+            clf._forward(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            clf._forward(x)
+        e1.record()
+        torch.cuda.synchronize()
+        chains_ms = e0.elapsed_time(e1) / reps
         timed.on = True
         for _ in range(reps):
             net(x)
@@ -114,7 +128,7 @@ def main():
     groups = {}
     for r in rows:
         groups[r["call"][:4].strip()] = round(groups.get(r["call"][:4].strip(), 0.0) + r["us"] / 1e3, 3)
-    print(json.dumps({"batch": batch, "forward_ms": round(whole_ms, 3), "own_kernels_ms": round(own, 3), "by_kind_ms": groups, "rows": rows}))
+    print(json.dumps({"batch": batch, "forward_ms": round(whole_ms, 3), "forward_two_chains_ms": round(chains_ms, 3), "own_kernels_ms": round(own, 3), "by_kind_ms": groups, "rows": rows}))
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ if [ "$part" = a ]; then
   python3 tools/pmc_summary.py $out $out/pmc_summary.json > $out/pmc_summary.txt
   rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
   step r4_cnn_layers.txt 200 python tools/bench_convs.py 4096 5
+  step r4_cnn_layers_8192.txt 200 python tools/bench_convs.py 8192 5
   head -4 $out/r4_kernel_stats_default_bench.csv | cut -c1-200
   cut -c1-300 $out/default.json
 else
