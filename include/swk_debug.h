@@ -89,8 +89,10 @@ int32_t swk_set_start_refine(swk_ctx *ctx, double tau);
 int32_t swk_prof_refined_windows(swk_ctx *ctx, int64_t *refined, int64_t *unrefined);
 
 /* ---- classifier kernels: A/B switches ---- */
-/* Measurement knob of the classifier kernels (A/B runs; results never depend on it).  knob 0: workgroup layout of the 1 x 1
- * kernel (0 = 16-wave workgroups, the default; 1 = 8 waves with the deepest activation ring that fits). */
+/* Measurement knobs of the classifier kernels (A/B runs).  knob 0: workgroup layout of the 1 x 1 kernel (0 = 16-wave workgroups, the
+ * default; 1 = 8 waves with the deepest activation ring that fits; results do not depend on it).  knob 1: 1 = the Fire modules' expand1x1
+ * shapes run on the split-bf16 kernel (float32 products as six bf16 MFMA products of three-way split operands: float32-accurate, another
+ * summation order); 0 = the default, the float32 kernel. */
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value);
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libswk.so")
-SOURCES = ["swk_api.hip", "ialm.hip", "ialm_mfma.hip", "ialm_mstate.hip", "ialm_small.hip", "ialm_refine.hip", "ialm_gram8.hip", "filters.hip", "ccl.hip", "classify_input.hip", "cnn_aux.hip", "cnn_conv1.hip", "cnn_conv1x1.hip", "cnn_conv3x3.hip", "cnn_wino3x3.hip", "cnn_poolsq.hip", "tracker.cpp", "roi_mask.cpp", "host_stage.cpp"]
+SOURCES = ["swk_api.hip", "ialm.hip", "ialm_mfma.hip", "ialm_mstate.hip", "ialm_small.hip", "ialm_refine.hip", "ialm_gram8.hip", "filters.hip", "ccl.hip", "classify_input.hip", "cnn_aux.hip", "cnn_conv1.hip", "cnn_conv1x1.hip", "cnn_expand_bf16.hip", "cnn_conv3x3.hip", "cnn_wino3x3.hip", "cnn_poolsq.hip", "tracker.cpp", "roi_mask.cpp", "host_stage.cpp"]
 HEADERS = ["swk_internal.h", "ialm_small_dev.h", os.path.join(ROOT, "include", "swk.h"), os.path.join(ROOT, "include", "swk_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", HERE]

@@ -169,6 +169,7 @@ static int launch_conv1x1_d(hipStream_t s, const float *src, int64_t rows, int s
     return hipGetLastError() == hipSuccess ? SWK_OK : SWK_ERR_HIP;
 }
 
+int g_expand_split_bf16 = getenv("SWK_EXPAND_SPLIT_BF16") ? atoi(getenv("SWK_EXPAND_SPLIT_BF16")) : 0;
 int g_conv1x1_ring = 0;          // A/B knob: 0 = 16-wave workgroups, column blocks of the wide expands split over two waves; 1 = the
                                  // first layout (8 waves, every wave all column blocks, activation ring as deep as fits)
 
@@ -228,6 +229,11 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     using namespace swk;
     const int64_t rows = (int64_t)n * h * w;
     hipStream_t s = (hipStream_t)stream;
+    if (g_expand_split_bf16 && cout == 4 * cin) {          // the Fire modules' expand1x1 shapes: float32 products from split bf16 operands
+        const int rc = launch_expand1x1_split_bf16(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x,
+                                                   c_off);
+        if (rc != SWK_ERR_ARG) return rc;
+    }
     switch ((cout + 31) / 32) {
     case 1: return launch_conv1x1<1>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
     case 2: return launch_conv1x1<2>(s, src, rows, sh, sw, cin, crop_y, crop_x, h, w, weight, bias, cout, dst, dH, dW, dC, off_y, off_x, c_off);
@@ -239,11 +245,13 @@ int32_t swk_nhwc_conv1x1_bias_relu_place(void *stream, const float *src, int32_t
     }
 }
 
-// Measurement knobs of the classifier kernels (A/B runs; results never depend on them).  knob 0: activation ring of the 1x1
-// kernel (0 = deepest that fits, 1 = one chunk in flight).
+// Measurement knobs of the classifier kernels (A/B runs).  knob 0: activation ring of the 1x1 kernel (0 = deepest that fits, 1 = one chunk
+// in flight; results do not depend on it).  knob 1: 1 = expand1x1 shapes on the split-bf16 kernel (cnn_expand_bf16.hip: float32-accurate,
+// another summation order than the float32 kernel's, so scores move in the last bits); 0, the default: every 1x1 on the float32 kernel.
 int32_t swk_set_cnn_tuning(int32_t knob, int32_t value)
 {
     if (knob == 0 && (value == 0 || value == 1)) { swk::g_conv1x1_ring = value; return SWK_OK; }
+    if (knob == 1 && (value == 0 || value == 1)) { swk::g_expand_split_bf16 = value; return SWK_OK; }
     return SWK_ERR_ARG;
 }
 

@@ -188,4 +188,9 @@ void launch_ccl_frame(hipStream_t s, const uint8_t *src, int F, int H, int W, in
 size_t ccl_words(int H, int W);
 size_t ccl_padded(int H, int W);
 
+
+// expand1x1 of the Fire shapes with float32 products formed from split bf16 operands (cnn_expand_bf16.hip); SWK_ERR_ARG for other shapes
+int launch_expand1x1_split_bf16(hipStream_t s, const float *src, int64_t rows, int sh, int sw, int cin, int crop_y, int crop_x, int h, int w,
+                                const float *wgt, const float *bias, int cout, float *dst, int dH, int dW, int dC, int off_y, int off_x, int c_off);
+extern int g_expand_split_bf16;          // A/B switch (swk_set_cnn_tuning knob 1): 1 = the split-bf16 kernel for the expand1x1 shapes
 }  // namespace swk

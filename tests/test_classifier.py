@@ -297,8 +297,10 @@ def test_gpu_model_pt_scores_and_decisions(golden_dir):
 
 
 @pytest.mark.gpu
-def test_fused_conv1x1_kernel_against_torch():
-    """swk_nhwc_conv1x1_bias_relu_place (convolution + bias + ReLU + placement on the f32 matrix cores) against
+@pytest.mark.parametrize("split_bf16", [0, 1])
+def test_fused_conv1x1_kernel_against_torch(split_bf16):
+    """(split_bf16 = 1: the expand1x1 shapes of the list on k_expand1x1_bf16s, swk_set_cnn_tuning knob 1 -- same placement, same tolerance.)
+    swk_nhwc_conv1x1_bias_relu_place (convolution + bias + ReLU + placement on the f32 matrix cores) against
     torch.nn.functional.conv2d on the shapes the Fire modules use and on ragged ones (pixel count not a multiple of 32,
     output channels not a multiple of 32, crop inside the source, channel offset in the destination).  float32 in a
     different summation order: 2e-5 relative to the output scale."""
@@ -317,6 +319,7 @@ def test_fused_conv1x1_kernel_against_torch():
         (700, 96, 16, 8, 0, 8, 8, 0, 16, 0), (1400, 16, 64, 10, 1, 8, 8, 0, 128, 64), (160, 48, 192, 12, 0, 12, 12, 0, 384, 0),
         (300, 48, 192, 12, 0, 12, 12, 0, 384, 192), (330, 512, 64, 9, 0, 9, 11, 1, 64, 0)]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.swk_set_cnn_tuning(1, split_bf16) == 0
     for n, cin, cout, sh, crop, size, dH, off, dC, c_off in cases:
         x = torch.randn((n, cin, sh, sh), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         wgt = (torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5).to(dev)
@@ -338,11 +341,50 @@ def test_fused_conv1x1_kernel_against_torch():
         mask = torch.ones_like(dst, dtype=torch.bool)
         mask[:, c_off:c_off + cout, off:off + size, off:off + size] = False
         assert bool((dst[mask] == -7.0).all())
+    assert lib.swk_set_cnn_tuning(1, 0) == 0
     # bad arguments are refused, not launched
     assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 4, 4, 24, 0, 0, 4, 4, wgt.data_ptr(), bias.data_ptr(), 8,
                                                 dst.data_ptr(), 4, 4, 8, 0, 0, 0) != 0          # cin not a multiple of 16
     assert lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), 1, 3, 3, 32, 0, 0, 3, 3, wgt.data_ptr(), bias.data_ptr(), 6,
                                                 dst.data_ptr(), 3, 3, 8, 0, 0, 0) != 0          # output channels not a multiple of 4
+
+
+@pytest.mark.gpu
+def test_split_bf16_expand_kernel_is_float32_accurate():
+    """k_expand1x1_bf16s (off by default; swk_set_cnn_tuning knob 1): every float32 product as six bf16 x bf16 MFMA products of three-way split
+    operands, accumulated in float32.  Against float64 its error must be that of a float32 multiply-add chain -- it is held to the error of the
+    float32 kernel (swk_set_cnn_tuning knob 1 = 0) on the same data, with a floor of 4e-7 of the output scale -- on post-ReLU
+    activations, on activations with a large dynamic range, and with a ragged last tile; and the two kernels place the same block."""
+    import ctypes
+    from swiftwatcher_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(31)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    worst = 0.0
+    try:
+        for n, cin, side, spread in ((67, 16, 8, 1.0), (131, 32, 12, 1.0), (40, 48, 10, 1.0), (300, 64, 14, 1.0), (33, 64, 9, 1e4), (5, 48, 3, 1e-3)):
+            cout = 4 * cin
+            x = torch.relu(torch.randn((n, cin, side, side), generator=g)) * 3.0
+            x = (x * torch.exp(torch.randn((n, 1, side, side), generator=g) * float(np.log(spread)) * 0.5)).to(dev).contiguous(memory_format=torch.channels_last)
+            wgt = (torch.randn((cout, cin), generator=g) * (2.0 / cin) ** 0.5).to(dev)
+            bias = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+            want = torch.relu(torch.einsum("nchw,kc->nkhw", x.double(), wgt.double()) + bias.double().view(1, -1, 1, 1))
+            scale = float(want.abs().max())
+            got = {}
+            for knob in (1, 0):
+                assert lib.swk_set_cnn_tuning(1, knob) == 0
+                dst = torch.zeros((n, cout, side, side), device=dev).contiguous(memory_format=torch.channels_last)
+                rc = lib.swk_nhwc_conv1x1_bias_relu_place(stream, x.data_ptr(), n, side, side, cin, 0, 0, side, side, wgt.data_ptr(), bias.data_ptr(),
+                                                          cout, dst.data_ptr(), side, side, cout, 0, 0, 0)
+                assert rc == 0
+                torch.cuda.synchronize()
+                got[knob] = float((dst.double() - want).abs().max()) / scale
+            worst = max(worst, got[1])
+            assert got[1] <= max(1.5 * got[0], 4e-7), (got, n, cin, spread)
+    finally:
+        lib.swk_set_cnn_tuning(1, 0)
+    assert worst < 2e-6
 
 
 @pytest.mark.gpu
